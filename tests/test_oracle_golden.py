@@ -1,0 +1,154 @@
+"""The CPU oracle against the golden vectors produced by the real reference
+(oracle/make_golden.py).  This is what pins the oracle: every later GPU parity
+test compares the HIP path with this oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import nmf as onmf, lasso as olasso, dictionary_learning as odl
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _tol(dtype):
+    # float64/complex128: same operations in the same order -> rounding only
+    # float32: the reference promotes some intermediates (see oracle/lasso.py)
+    return 1.0e-9 if np.dtype(dtype).itemsize >= 8 and np.dtype(dtype) != np.complex64 else 2.0e-4
+
+
+def _close(a, b, tol):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    scale = max(1.0, float(np.max(np.abs(b)))) if b.size else 1.0
+    return float(np.max(np.abs(a - b))) <= tol * scale if a.size else True
+
+
+# ------------------------------------------------------------------ NMF ----
+def _nmf_cases(golden_dir):
+    g = _load(golden_dir, 'nmf_golden.npz')
+    return g, [str(c) for c in g['cases']]
+
+
+def test_nmf_trace_and_solve(golden_dir):
+    g, cases = _nmf_cases(golden_dir)
+    assert len(cases) == 24
+    for name in cases:
+        base, mtag = name.rsplit('_', 1)
+        y, D0 = g[base + '/y'], g[base + '/D0']
+        mask = g[base + '/mask'] if mtag == 'mask' else None
+        lik = 'kl' if '_kl' in base else 'l2'
+        tol = _tol(y.dtype)
+        # per-iteration trace
+        n = len(g[name + '/trace_maxdiff'])
+        D = oracle.common.l2_strict(D0)
+        x = np.ones((y.shape[0], D0.shape[0]), dtype=y.dtype)
+        for i in range(n):
+            x, D, diff = onmf.mu_step(y, x, D, mask, lik)
+            ref = g[name + '/trace_maxdiff'][i]
+            assert abs(diff - ref) <= tol * max(1.0, abs(ref)) + (1e-12 if tol < 1e-6 else 1e-6), (name, i)
+            res = onmf.residual(y, x, D, mask)
+            assert abs(res - g[name + '/trace_resid'][i]) <= max(tol, 1e-5 if y.dtype == np.float32 else 0) * g[name + '/trace_resid'][i] + 1e-12, (name, i)
+        assert _close(D, g[name + '/trace_D'], tol), name
+        assert _close(x, g[name + '/trace_x'], tol), name
+        assert x.dtype == y.dtype and D.dtype == y.dtype
+        # full solve
+        it, Df, xf = onmf.solve(y, D0.copy(), tol=float(g[name + '/tol']),
+                                maxiter=400, likelihood=lik, mask=mask)
+        if y.dtype == np.float64:
+            assert it == int(g[name + '/it']), name
+            assert _close(Df, g[name + '/D'], tol), name
+            assert _close(xf, g[name + '/x'], tol), name
+        else:
+            # float32: the stop iteration may move by rounding near tol
+            assert abs(it - int(g[name + '/it'])) <= 3, name
+
+
+def test_nmf_gram_formulation_drift(golden_dir):
+    """The product computes x.(DD^T) and (x^T x).D; quantify the drift of that
+    reformulation against the reference formulation (float32, 25 iterations):
+    must stay far inside the 1e-5 residual tolerance of BASELINE.json."""
+    g, _ = _nmf_cases(golden_dir)
+    base = 'nmf_256x128k8_float32_l2'
+    y, D0 = g[base + '/y'], g[base + '/D0']
+    D = oracle.common.l2_strict(D0)
+    x = np.ones((256, 8), np.float32)
+    ref = g[base + '_nomask/trace_resid']
+    for i in range(len(ref)):
+        x, D, _ = onmf.mu_step_gram(y, x, D)
+        assert abs(onmf.residual(y, x, D) - ref[i]) <= 1.0e-5 * ref[i]
+
+
+# ---------------------------------------------------------------- LASSO ----
+def test_lasso_prox_known_answers(golden_dir):
+    g = _load(golden_dir, 'lasso_golden.npz')
+    z = g['prox/z']
+    # tests/test_lasso.py:21-33 hand values
+    assert np.allclose(olasso.shrink_real(np.array([0.1, -2.0, 1.4]), 1.0),
+                       [0.0, -1.0, 0.4])
+    assert np.allclose(olasso.shrink_real(z, 1.0), [[0.0, -1.0, 0.4], [0.1, 2.0, -0.4]])
+    assert np.allclose(olasso.shrink_real(z, 1.0), g['prox/real'])
+    assert np.allclose(olasso.shrink_complex(z + z * 1.0j, 1.0), g['prox/complex45'])
+    assert np.allclose(olasso.shrink_positive(z, 1.0), g['prox/positive'])
+    # 90 degrees: shrinking i*z equals i*shrink(z)   (tests/test_lasso.py:42-45)
+    zz = np.array([0.1, -2.0, 1.4])
+    assert np.allclose(olasso.shrink_complex(zz * 1.0j, 1.0),
+                       olasso.shrink_complex(zz + 0.0j, 1.0) * 1.0j)
+
+
+def test_lasso_all_cases(golden_dir):
+    g = _load(golden_dir, 'lasso_golden.npz')
+    cases = [str(c) for c in g['cases']]
+    assert len(cases) == 360
+    for name in cases:
+        base, mname, method, tag = name.split('/')
+        y, A = g[base + '/y'], g[base + '/A']
+        mask = None if mname == 'nomask' else g[base + '/' + mname]
+        it, x = olasso.solve(y.copy(), A.copy(), float(g[name + '/alpha']),
+                             tol=float(g[name + '/tol']), method=method,
+                             maxiter=int(g[name + '/maxiter']),
+                             mask=None if mask is None else mask.copy())
+        xr = g[name + '/x']
+        if y.dtype == np.float32:
+            # reference promotes fista to float64 (NumPy>=2); compare loosely
+            assert _close(x, xr, 5.0e-4), name
+            if tag == 'exh':
+                assert it == int(g[name + '/it']), name
+        else:
+            assert it == int(g[name + '/it']), name
+            assert _close(x, xr, 1.0e-9), name
+        assert x.shape == xr.shape
+
+
+# ------------------------------------------------- dictionary learning -----
+def test_dictionary_learning_all_cases(golden_dir):
+    g = _load(golden_dir, 'dl_golden.npz')
+    cases = [str(c) for c in g['cases']]
+    assert len(cases) == 68
+    for name in cases:
+        parts = name.split('/')
+        base = parts[0]
+        y, D0, mask = g[base + '/y'], g[base + '/D0'], g[base + '/mask']
+        if parts[1] == 'reftest':
+            it, D, x = odl.solve(y.copy(), D0.copy(), 0.1, tol=1.0e-4,
+                                 minibatch=100, maxiter=1000,
+                                 lasso_method='acc_ista', lasso_iter=1000,
+                                 random_seed=0)
+        else:
+            minibatch = int(parts[1][2:])
+            lm = parts[2].rstrip('0123456789')
+            li = int(parts[2][len(lm):])
+            use_mask = parts[3] == 'mask'
+            epochs = int(parts[4][2:])
+            yy = y * mask if use_mask else y
+            it, D, x = odl.solve(yy.copy(), D0.copy(), 0.1, tol=0.0,
+                                 minibatch=minibatch, maxiter=epochs + 1,
+                                 lasso_method=lm, lasso_iter=li,
+                                 lasso_tol=1.0e-5, random_seed=0,
+                                 mask=mask.copy() if use_mask else None)
+        assert it == int(g[name + '/it']), name
+        assert _close(D, g[name + '/D'], 1.0e-9), name
+        assert _close(x, g[name + '/x'], 1.0e-9), name
