@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the headline metric (BASELINE.json): NMF multiplicative-update
+iterations/s at Y = 65536 x 4096, k = 256, float32, on N GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is ONE MU iteration (x update, D update, l2_strict, max|dD| stop test) of the
+whole job; rows of Y / x are sharded over the ranks (strong scaling: the problem size is
+fixed) and the [K, F+K] statistics are all-reduced once per step (RCCL).  Inputs are
+synthetic (SURVEY 8d recipe) and resident in HBM before the timed region.
+
+Rank 0 prints one JSON line.  `roofline` is the dominant kernel (the fused
+Y.D^T + quotient GEMM) timed with HIP events on the solver's own stream inside the timed
+steps; `cpu_baseline` is the NumPy oracle (the reference's formulation) on a bounded
+sample of the same workload on this host's cores (N = 1, rank 0 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_ROWS, N_FEAT, N_ATOMS = 65536, 4096, 256
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth(n_rows, rank_seed, device):
+    """Y = xt.Dt + 0.1|noise| (>= 0), D0 = max(Dt + 0.3 noise, 0.1): SURVEY 8d, C2.
+    Generated on the GPU (data synthesis only; not part of the measured path)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(1234)                       # Dt / D0 identical on every rank
+    Dt = torch.randn((N_ATOMS, N_FEAT), generator=g, device=device).clamp_(min=0)
+    D0 = (Dt + 0.3 * torch.randn((N_ATOMS, N_FEAT), generator=g, device=device)).clamp_(min=0.1)
+    g.manual_seed(99 + rank_seed)             # this rank's rows
+    xt = torch.randn((n_rows, N_ATOMS), generator=g, device=device).clamp_(min=0)
+    Y = xt @ Dt
+    Y += 0.1 * torch.randn((n_rows, N_FEAT), generator=g, device=device).abs_()
+    del xt
+    return Y, D0
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle (NumPy restatement of the reference's 6-GEMM formulation) on a bounded
+    row sample of the same workload, scaled to whole-job iterations/s."""
+    import numpy as np
+    from oracle import nmf as onmf, common
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    rows = 4096
+    rng = np.random.RandomState(0)
+    Dt = np.maximum(rng.randn(N_ATOMS, N_FEAT), 0).astype(np.float32)
+    xt = np.maximum(rng.randn(rows, N_ATOMS), 0).astype(np.float32)
+    y = xt @ Dt + 0.1 * np.abs(rng.randn(rows, N_FEAT)).astype(np.float32)
+    D = common.l2_strict(np.maximum(Dt + 0.3 * rng.randn(N_ATOMS, N_FEAT), 0.1).astype(np.float32))
+    x = np.ones((rows, N_ATOMS), np.float32)
+    x, D, _ = onmf.mu_step(y, x, D)           # warm-up (BLAS threads, page faults)
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < 3 or (time.perf_counter() - t0 < budget_s and iters < 40):
+        x, D, _ = onmf.mu_step(y, x, D)
+        iters += 1
+    per_iter = (time.perf_counter() - t0) / iters
+    scale = N_ROWS / rows
+    return {'value': 1.0 / (per_iter * scale), 'unit': 'iterations/s', 'cores': cores,
+            'kind': 'port',
+            'sample': 'oracle.nmf.mu_step (NumPy/BLAS, reference 6-GEMM formulation), %d of '
+                      '%d rows x %d iterations, time scaled x%d' % (rows, N_ROWS, iters, scale)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from decomp_amd import _arrays, _hip, sharded
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=device)
+
+    rows = N_ROWS // world
+    Y, D0 = synth(rows, rank, device)
+    x = torch.ones((rows, N_ATOMS), dtype=torch.float32, device=device)
+    D = D0.clone()
+    _arrays.l2_normalize_(D, strict=True)
+    torch.cuda.synchronize()
+
+    lib, h = _arrays.lib_handle(D)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(n_steps):
+        """n_steps MU iterations (tol = 0: the stop test is evaluated, never met)."""
+        if world == 1:
+            it = ctypes.c_int(0)
+            rc = lib.dcp_nmf_mu_f32(h, _arrays.ptr(Y), None, _arrays.ptr(x), _arrays.ptr(D),
+                                    rows, N_FEAT, N_ATOMS, _hip.LIK_L2, ctypes.c_float(0.0),
+                                    n_steps + 1, ctypes.byref(it), None, None)
+            _hip.check(h, rc, 'dcp_nmf_mu_f32')
+            assert it.value == n_steps + 1
+            return D
+        backend = sharded.HipStepBackend(Y, None, x, D, _hip.LIK_L2)
+        it, Dout = sharded.mu_loop(backend, D, 0.0, n_steps + 1, world_size=world,
+                                   new_like=torch.empty_like)
+        assert it == n_steps + 1
+        return Dout
+
+    Dcur = run(args.warmup)
+    if Dcur is not D:
+        D.copy_(Dcur)
+    _hip.check(h, lib.dcp_profile_reset(h), 'profile_reset')
+    _hip.check(h, lib.dcp_profile_enable(h, 1), 'profile_enable')
+    barrier()
+    t0 = time.perf_counter()
+    Dcur = run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _hip.check(h, lib.dcp_profile_enable(h, 0), 'profile_enable')
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # per-kernel-group event timings of the timed steps (this rank)
+    prof = {}
+    for lab in range(_hip.PROF_NLABELS):
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        _hip.check(h, lib.dcp_profile_read(h, lab, ctypes.byref(ms), ctypes.byref(cnt)), 'profile_read')
+        if cnt.value:
+            prof[lib.dcp_profile_label_name(lab).decode()] = {
+                'ms_total': ms.value, 'launches': cnt.value, 'ms_avg': ms.value / cnt.value}
+
+    finite = bool(torch.isfinite(Dcur).all().item()) and bool(torch.isfinite(x).all().item())
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        W = 4.0 * N_ROWS * N_ATOMS * N_FEAT + 4.0 * N_ROWS * N_ATOMS ** 2 + 4.0 * N_ATOMS ** 2 * N_FEAT
+        out = {
+            'metric': 'nmf_mu_iterations_per_s', 'value': args.steps / elapsed,
+            'unit': 'iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'nmf_mu l2 no-mask Y=65536x4096 k=256 fp32 (BASELINE configs[1])',
+                       'rows_per_gpu': rows, 'parallelism': 'rows sharded x%d, 1 all-reduce/step' % world},
+            'algorithmic_tflops': W / (elapsed / args.steps) / 1e12,
+            'mfma_roofline_frac_whole_step': W / (elapsed / args.steps) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+            'finite': finite,
+            'kernel_ms_avg': {k: round(v['ms_avg'], 4) for k, v in prof.items()},
+        }
+        # dominant kernel: the fused Y.D^T GEMM + MU quotient (2.N.K.F flop per launch)
+        dom = prof.get('x_update')
+        if dom:
+            flops = 2.0 * rows * N_ATOMS * N_FEAT
+            ach = flops / (dom['ms_avg'] * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel<NT, EpiMuNum> (Y.D^T + quotient)',
+                               'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                               'launch_ms': dom['ms_avg'], 'launches': dom['launches']}
+        st = prof.get('stats')
+        if st:
+            flops = 2.0 * rows * N_ATOMS * (N_FEAT + N_ATOMS)
+            ach = flops / (st['ms_avg'] * 1e-3) / 1e12
+            out['roofline_stats_gemm'] = {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel<TN, EpiSlab> (x^T.[Y|x])',
+                                          'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
+                                          'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                                          'launch_ms': st['ms_avg']}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,296 @@
+// fp32 MFMA GEMM core for gfx950 (MI355X), written for 64-wide wavefronts.
+//
+//   C(m, n) = sum_k A(m, k) * B(k, n)        (reduction index k)
+//
+// Instruction: v_mfma_f32_32x32x2_f32 (exact f32, 64 cycles / SIMD / instr).
+// A workgroup is 256 threads = 4 waves; each wave owns a WM x WN sub-tile made
+// of (WM/32) x (WN/32) MFMA 32x32 accumulators.  Operand panels are staged
+// global -> registers -> LDS (double buffered, one barrier per K block) so the
+// next block's HBM/L2 latency hides under the current block's MFMAs.
+//
+// Operand memory layouts (both for A and for B):
+//   KMAJOR : element (row, k) at p[row * ld + k]   (reduction index contiguous)
+//   XMAJOR : element (row, k) at p[k * ld + row]   (row index contiguous)
+// "row" is m for A and n for B.  So
+//   NT  (A KMAJOR, B KMAJOR):  Y . D^T,  D . D^T,  y . A^H
+//   NN  (A KMAJOR, B XMAJOR):  x . G,  x . D,  S . D
+//   TN  (A XMAJOR, B XMAJOR):  x^T . Y,  x^T . x   (reduction over samples)
+//
+// LDS images:
+//   KMAJOR panel: [rows][BK + 4] floats.  Each lane fetches 4 consecutive k of
+//     its row with one ds_read_b128; the +4 pad makes the 16-lane b128 groups
+//     hit 16 distinct 4-bank slots (row stride 20 dwords -> 5r mod 16 distinct).
+//   XMAJOR panel: [BK][rows] floats, read with ds_read_b32 (32 consecutive
+//     dwords per half wave: conflict free).
+// k order inside a K block: the lane half h = lane >> 5 of MFMA step (c, j)
+// consumes k = 8c + 4h + j.  Any fixed permutation of k is a valid fp32 fma
+// chain; this one lets a KMAJOR lane read its 4 k's as one 16-byte load.
+//
+// Split-K: grid = tiles_m * tiles_n * ksplits; split s reduces
+// k in [s*klen, min(K, (s+1)*klen)).  The epilogue receives the split index.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dcp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { KMAJOR = 0, XMAJOR = 1 };
+
+struct GemmProblem {
+    const float* A;
+    long lda;
+    const float* B;   // columns [0, n_b1)
+    long ldb;
+    const float* B2;  // columns [n_b1, N) (optional second segment), may be null
+    long ldb2;
+    int n_b1;
+    int M, N, K;
+    int ksplits, klen;
+    int tiles_m, tiles_n;
+    int mt_fast;  // 1: consecutive logical ids walk m tiles first
+};
+
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_>
+struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_;
+};
+
+// blocks b and b+8 share an XCD (round-robin dispatch).  Give every XCD a
+// contiguous run of logical ids so neighbouring tiles share that XCD's L2.
+// Bijective for any n (guide T1).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, within = id >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + within;
+}
+
+template <int LAY, int ROWS, int BK>
+struct PanelGeom {
+    static constexpr int STRIDE = (LAY == KMAJOR) ? (BK + 4) : ROWS;
+    static constexpr int LINES = (LAY == KMAJOR) ? ROWS : BK;
+    static constexpr int ELEMS = STRIDE * LINES;
+    static constexpr int F4 = ROWS * BK / 4 / 256;  // float4 per thread per block
+    static_assert(ROWS * BK % 1024 == 0, "panel must be a multiple of 256 float4");
+};
+
+// Loads one panel block into registers.  EDGE: scalar, predicated, any alignment.
+template <int LAY, int ROWS, int BK, bool EDGE, int F4>
+__device__ __forceinline__ void panel_gload(f32x4 (&r)[F4],
+                                            const float* __restrict__ p, long ld, int row0,
+                                            int nrows, int k0, int kend, int tid) {
+    static_assert(F4 == PanelGeom<LAY, ROWS, BK>::F4, "register panel size");
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+        const int idx = tid + i * 256;
+        if (LAY == KMAJOR) {
+            const int row = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
+            const float* src = p + (long)(row0 + row) * ld + (k0 + kq);
+            if (!EDGE) {
+                r[i] = *reinterpret_cast<const f32x4*>(src);
+            } else {
+                const bool rok = (row0 + row) < nrows;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    r[i][e] = (rok && (k0 + kq + e) < kend) ? src[e] : 0.0f;
+            }
+        } else {
+            const int kr = idx / (ROWS / 4), rq = (idx % (ROWS / 4)) * 4;
+            const float* src = p + (long)(k0 + kr) * ld + (row0 + rq);
+            if (!EDGE) {
+                r[i] = *reinterpret_cast<const f32x4*>(src);
+            } else {
+                const bool kok = (k0 + kr) < kend;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    r[i][e] = (kok && (row0 + rq + e) < nrows) ? src[e] : 0.0f;
+            }
+        }
+    }
+}
+
+template <int LAY, int ROWS, int BK, int F4>
+__device__ __forceinline__ void panel_lds_store(float* s, const f32x4 (&r)[F4], int tid) {
+    static_assert(F4 == PanelGeom<LAY, ROWS, BK>::F4, "register panel size");
+    constexpr int STRIDE = PanelGeom<LAY, ROWS, BK>::STRIDE;
+#pragma unroll
+    for (int i = 0; i < F4; ++i) {
+        const int idx = tid + i * 256;
+        if (LAY == KMAJOR) {
+            const int row = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
+            *reinterpret_cast<f32x4*>(s + row * STRIDE + kq) = r[i];
+        } else {
+            const int kr = idx / (ROWS / 4), rq = (idx % (ROWS / 4)) * 4;
+            *reinterpret_cast<f32x4*>(s + kr * STRIDE + rq) = r[i];
+        }
+    }
+}
+
+// Fragment for MFMA steps (c, 0..3): lane (l31, h) gets element (row, k=8c+4h+j) in [j].
+template <int LAY, int ROWS, int BK>
+__device__ __forceinline__ f32x4 panel_frag(const float* s, int row, int c, int h) {
+    constexpr int STRIDE = PanelGeom<LAY, ROWS, BK>::STRIDE;
+    if (LAY == KMAJOR) {
+        return *reinterpret_cast<const f32x4*>(s + row * STRIDE + c * 8 + 4 * h);
+    } else {
+        f32x4 v;
+        const float* q = s + (c * 8 + 4 * h) * STRIDE + row;
+        v[0] = q[0];
+        v[1] = q[STRIDE];
+        v[2] = q[2 * STRIDE];
+        v[3] = q[3 * STRIDE];
+        return v;
+    }
+}
+
+template <class Cfg, int ALAY, int BLAY, bool EDGE, class Epi>
+__global__ void __launch_bounds__(256, Cfg::MINW) gemm_mfma_kernel(GemmProblem p, Epi epi) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, WM = Cfg::WM, WN = Cfg::WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    static_assert(BK % 8 == 0, "BK multiple of 8");
+    typedef PanelGeom<ALAY, BM, BK> GA;
+    typedef PanelGeom<BLAY, BN, BK> GB;
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (GA::ELEMS + GB::ELEMS)];
+    float* sA0 = smem;
+    float* sB0 = smem + 2 * GA::ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // ---- tile decode (XCD aware) ------------------------------------------
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int split = lid / tiles;
+    const int t = lid - split * tiles;
+    int mt, nt;
+    if (p.mt_fast) {
+        mt = t % p.tiles_m;
+        nt = t / p.tiles_m;
+    } else {
+        nt = t % p.tiles_n;
+        mt = t / p.tiles_n;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kbeg = split * p.klen;
+    const int kend = min(p.K, kbeg + p.klen);
+
+    // B may be two column segments laid side by side ([Y | x] in the TN stats GEMM)
+    const float* Bp = p.B;
+    long ldb = p.ldb;
+    int nB0 = n0, nBrows = p.n_b1;
+    if (p.B2 != nullptr && n0 >= p.n_b1) {
+        Bp = p.B2;
+        ldb = p.ldb2;
+        nB0 = n0 - p.n_b1;
+        nBrows = p.N - p.n_b1;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 ra[GA::F4], rb[GB::F4];
+    const int nkb = (kend - kbeg + BK - 1) / BK;
+
+    if (nkb > 0) {
+        panel_gload<ALAY, BM, BK, EDGE>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+        panel_gload<BLAY, BN, BK, EDGE>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
+        panel_lds_store<ALAY, BM, BK>(sA0, ra, tid);
+        panel_lds_store<BLAY, BN, BK>(sB0, rb, tid);
+    }
+    __syncthreads();
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int cur = kb & 1;
+        const float* sA = sA0 + cur * GA::ELEMS;
+        const float* sB = sB0 + cur * GB::ELEMS;
+        const bool more = (kb + 1) < nkb;
+        if (more) {  // issue next block's global loads; they land during the MFMAs
+            const int k0 = kbeg + (kb + 1) * BK;
+            panel_gload<ALAY, BM, BK, EDGE>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+            panel_gload<BLAY, BN, BK, EDGE>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+        }
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = panel_frag<ALAY, BM, BK>(sA, wm * WM + i * 32 + l31, c, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = panel_frag<BLAY, BN, BK>(sB, wn * WN + j * 32 + l31, c, h);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s],
+                                                                         acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            panel_lds_store<ALAY, BM, BK>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
+            panel_lds_store<BLAY, BN, BK>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31,
+    //      row = (r&3) + 8*(r>>2) + 4*(lane>>5) ------------------------------
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (!EDGE || (row < p.M && col < p.N)) epi(row, col, acc[i][j][r], split);
+            }
+        }
+    }
+}
+
+// Host-side launch helper.  Picks EDGE when any fast-path precondition fails.
+template <class Cfg, int ALAY, int BLAY, class Epi>
+inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi& epi) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    if (p.ksplits < 1) p.ksplits = 1;
+    if (p.ksplits == 1) {
+        p.klen = ((p.K + BK - 1) / BK) * BK;
+        if (p.klen == 0) p.klen = BK;
+    }
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    // every split range [s*klen, min(K, (s+1)*klen)) is then a whole number of K blocks
+    bool fast = (p.M % BM == 0) && (p.N % BN == 0) && (p.K % BK == 0) && (p.klen % BK == 0) &&
+                (p.lda % 4 == 0) && (p.ldb % 4 == 0) && al16(p.A) && al16(p.B) && p.K > 0;
+    if (p.B2 != nullptr)
+        fast = fast && (p.n_b1 % BN == 0) && (p.ldb2 % 4 == 0) && al16(p.B2);
+    else
+        p.n_b1 = p.N;
+    const int grid = p.tiles_m * p.tiles_n * p.ksplits;
+    if (grid <= 0) return hipSuccess;
+    if (fast)
+        hipLaunchKernelGGL((gemm_mfma_kernel<Cfg, ALAY, BLAY, false, Epi>), dim3(grid), dim3(256),
+                           0, stream, p, epi);
+    else
+        hipLaunchKernelGGL((gemm_mfma_kernel<Cfg, ALAY, BLAY, true, Epi>), dim3(grid), dim3(256),
+                           0, stream, p, epi);
+    return hipGetLastError();
+}
+
+}  // namespace dcp

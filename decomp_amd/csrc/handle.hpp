@@ -1,0 +1,153 @@
+// Opaque library handle: device binding, stream, grow-only device workspace and
+// pinned host scalars for read-backs.  One handle per process/device; calls on one
+// handle are not re-entrant.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/decomp_hip.h"
+
+struct dcp_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // Workspace: one grow-only arena.  A public call plans its total need, reserves it
+    // (ws_reserve: reallocates only when the plan outgrows the arena, i.e. on the first
+    // call of a given problem size, never in steady state), then bumps (ws_alloc).
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    size_t arena_used = 0;
+    // pinned host scratch for scalar read-backs
+    void* host_pinned = nullptr;
+    size_t host_pinned_bytes = 0;
+    std::string err;
+    // optional per-kernel timing (dcp_profile_*): hipEvent pairs around labelled launches
+    bool prof_on = false;
+    struct ProfRec { int label; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[DCP_PROF_NLABELS] = {0};
+    long long prof_cnt[DCP_PROF_NLABELS] = {0};
+};
+
+namespace dcp {
+
+inline int fail(dcp_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define DCP_HIP_OK(h, expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return dcp::fail((h), DCP_ERR_HIP,                                               \
+                             std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+#define DCP_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != DCP_OK) return _rc; \
+    } while (0)
+
+// Times everything enqueued on the handle's stream during its lifetime under `label`
+// (only when profiling is on; otherwise free).
+struct ProfScope {
+    dcp_handle* h;
+    int label;
+    hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t take(dcp_handle* h) {
+        if (!h->prof_pool.empty()) {
+            hipEvent_t e = h->prof_pool.back();
+            h->prof_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    ProfScope(dcp_handle* h_, int label_) : h(h_), label(label_) {
+        if (!h->prof_on) return;
+        a = take(h);
+        b = take(h);
+        if (a) (void)hipEventRecord(a, h->stream);
+    }
+    ~ProfScope() {
+        if (!a || !b) return;
+        (void)hipEventRecord(b, h->stream);
+        h->prof_recs.push_back({label, a, b});
+    }
+};
+
+inline void ws_reset(dcp_handle* h) {
+    h->arena_used = 0;
+}
+
+// Reserve the total workspace for a call up front (so no allocation happens
+// between kernels).  Returns DCP_OK or an error code.
+inline int ws_reserve(dcp_handle* h, size_t bytes) {
+    if (bytes <= h->arena_bytes) return DCP_OK;
+    if (h->arena) {
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) return fail(h, DCP_ERR_HIP, hipGetErrorString(e));
+        (void)hipFree(h->arena);
+        h->arena = nullptr;
+        h->arena_bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 3) + (1u << 20);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        want = bytes;
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess)
+        return fail(h, DCP_ERR_NOMEM,
+                    "workspace hipMalloc of " + std::to_string(bytes) + " bytes failed: " +
+                        hipGetErrorString(e));
+    h->arena = static_cast<char*>(p);
+    h->arena_bytes = want;
+    h->arena_used = 0;
+    return DCP_OK;
+}
+
+inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+
+// Bump allocation from the reserved arena; nullptr when the reservation was too small
+// (a library bug, reported by the caller as DCP_ERR_INTERNAL).
+template <class T>
+inline T* ws_alloc(dcp_handle* h, size_t count) {
+    const size_t bytes = align256(count * sizeof(T));
+    if (h->arena_used + bytes > h->arena_bytes) return nullptr;
+    T* p = reinterpret_cast<T*>(h->arena + h->arena_used);
+    h->arena_used += bytes;
+    return p;
+}
+
+// Sizing helper mirroring ws_alloc.
+struct WsPlan {
+    size_t total = 0;
+    template <class T>
+    void add(size_t count) {
+        total += align256(count * sizeof(T));
+    }
+};
+
+inline int host_scratch(dcp_handle* h, size_t bytes, void** out) {
+    if (bytes > h->host_pinned_bytes) {
+        if (h->host_pinned) (void)hipHostFree(h->host_pinned);
+        h->host_pinned = nullptr;
+        h->host_pinned_bytes = 0;
+        size_t want = bytes < 4096 ? 4096 : bytes;
+        hipError_t e = hipHostMalloc(&h->host_pinned, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(h, DCP_ERR_NOMEM, "hipHostMalloc failed");
+        h->host_pinned_bytes = want;
+    }
+    *out = h->host_pinned;
+    return DCP_OK;
+}
+
+}  // namespace dcp

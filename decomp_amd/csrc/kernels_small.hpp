@@ -1,0 +1,244 @@
+// Small HBM-bound kernels around the GEMM cores: split-K slab reduction, row
+// normalisation (+ max|dD|), elementwise products / quotients, column sums,
+// sign scans.  All are deterministic (no float atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "scalar.hpp"
+
+namespace dcp {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+template <class R>
+__device__ __forceinline__ R wave_max(R v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        R w = __shfl_down(v, o, 64);
+        v = (w > v || w != w) ? w : v;  // NaN propagates, as in np.max
+    }
+    return v;
+}
+
+// Block-wide reductions for 256-thread blocks; result valid in thread 0.
+template <class R>
+__device__ __forceinline__ R block_sum_256(R v, R* sh /* >= 4 */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    R r = 0;
+    if (threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+template <class R>
+__device__ __forceinline__ R block_max_256(R v, R* sh) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    R r = 0;
+    if (threadIdx.x == 0) {
+        r = sh[0];
+        for (int i = 1; i < 4; ++i) r = (sh[i] > r || sh[i] != sh[i]) ? sh[i] : r;
+    }
+    __syncthreads();
+    return r;
+}
+
+// out[i] = sum_s slabs[s*stride + i], s in fixed order 0..S-1 (bitwise reproducible).
+template <class T>
+__global__ void __launch_bounds__(256) reduce_slabs_kernel(const T* __restrict__ slabs, long stride,
+                                                           int S, long count, T* __restrict__ out) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < count; i += (long)gridDim.x * 256L) {
+        T acc = slabs[i];
+        for (int s = 1; s < S; ++s) acc = add(acc, slabs[(long)s * stride + i]);
+        out[i] = acc;
+    }
+}
+
+// Same, for a [rows, cols] matrix written into a wider destination (leading dim ld_out).
+template <class T>
+__global__ void __launch_bounds__(256) reduce_slabs_rows_kernel(const T* __restrict__ slabs,
+                                                                long stride, int S, long rows,
+                                                                long cols, T* __restrict__ out,
+                                                                long ld_out) {
+    const long count = rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < count; i += (long)gridDim.x * 256L) {
+        T acc = slabs[i];
+        for (int s = 1; s < S; ++s) acc = add(acc, slabs[(long)s * stride + i]);
+        const long r = i / cols, c = i - r * cols;
+        out[r * ld_out + c] = acc;
+    }
+}
+
+// out[r, c] = v[r] for c in [0, cols)  (a per-row value broadcast along the row)
+template <class T>
+__global__ void __launch_bounds__(256) bcast_rows_kernel(const T* __restrict__ v, long rows,
+                                                         long cols, T* __restrict__ out,
+                                                         long ld_out) {
+    const long count = rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < count; i += (long)gridDim.x * 256L) {
+        const long r = i / cols, c = i - r * cols;
+        out[r * ld_out + c] = v[r];
+    }
+}
+
+// out = a o b (elementwise; b real "mask" of the same shape, or broadcast along rows when
+// b_row_stride == 0).
+template <class T>
+__global__ void __launch_bounds__(256) mul_mask_kernel(const T* __restrict__ a,
+                                                       const real_t<T>* __restrict__ m, long rows,
+                                                       long cols, long m_row_stride,
+                                                       T* __restrict__ out) {
+    const long n = rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const long r = i / cols, c = i - r * cols;
+        out[i] = scale(a[i], m[r * m_row_stride + c]);
+    }
+}
+
+// out = cur * max(num, 0) / max(den, eps)   (grads.py:84,93), arbitrary leading dims.
+// den_bcast: 0 = full [rows, cols]; 1 = one value per row (den[row]); 2 = one per column.
+template <class T>
+__global__ void __launch_bounds__(256) mu_quotient_kernel(const T* __restrict__ cur, long ld_cur,
+                                                          const T* __restrict__ num, long ld_num,
+                                                          const T* __restrict__ den, long ld_den,
+                                                          int den_bcast, long rows, long cols,
+                                                          T* __restrict__ out, long ld_out) {
+    const long n = rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const long r = i / cols, c = i - r * cols;
+        const T d = den_bcast == 0 ? den[r * ld_den + c] : (den_bcast == 1 ? den[r] : den[c]);
+        const T nu = num[r * ld_num + c];
+        out[r * ld_out + c] =
+            cur[r * ld_cur + c] * (nu > T(0) ? nu : T(0)) / (d > T(1.0e-15) ? d : T(1.0e-15));
+    }
+}
+
+// One workgroup per row of U[K, F]:  out = U / sqrt(sum |U|^2)  (strict) or
+// U / sqrt(max(sum |U|^2, 1)).  Optionally block-max of |ref - out| into rowmax[row].
+template <class T>
+__global__ void __launch_bounds__(256) row_normalize_kernel(const T* __restrict__ U, long ld_u,
+                                                            long F, int strict,
+                                                            const T* __restrict__ ref, long ld_ref,
+                                                            T* __restrict__ out, long ld_out,
+                                                            real_t<T>* __restrict__ rowmax) {
+    typedef real_t<T> R;
+    __shared__ R sh[4];
+    __shared__ R s_inv;
+    const long row = blockIdx.x;
+    const T* u = U + row * ld_u;
+    R acc = 0;
+    for (long j = threadIdx.x; j < F; j += 256) acc += abs2(u[j]);
+    R tot = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) {
+        if (!strict) tot = tot > R(1) ? tot : R(1);
+        s_inv = sqrt(tot);
+    }
+    __syncthreads();
+    const R nrm = s_inv;
+    R md = 0;
+    for (long j = threadIdx.x; j < F; j += 256) {
+        const T v = u[j];
+        T o;  // a true division, as the reference's U / sqrt(.)
+        if constexpr (scalar_traits<T>::is_complex) {
+            o.re = v.re / nrm;
+            o.im = v.im / nrm;
+        } else {
+            o = v / nrm;
+        }
+        if (ref != nullptr) {
+            const R d = absval(sub(ref[row * ld_ref + j], o));
+            md = (d > md || d != d) ? d : md;
+        }
+        out[row * ld_out + j] = o;
+    }
+    if (rowmax != nullptr) {
+        R m = block_max_256(md, sh);
+        if (threadIdx.x == 0) rowmax[row] = m;
+    }
+}
+
+// Single block: out[0] = max_i v[i] (v >= 0); NaN propagates (np.max semantics).
+template <class R>
+__global__ void __launch_bounds__(256) final_max_kernel(const R* __restrict__ v, long n,
+                                                        R* __restrict__ out) {
+    __shared__ R sh[4];
+    R m = 0;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const R x = v[i];
+        m = (x > m || x != x) ? x : m;
+    }
+    R r = block_max_256(m, sh);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+// count of elements failing `x >= 0` (so NaN counts, exactly as assertion.py:99-100 fails on
+// it); two stage, deterministic: partial[block], then summed by the caller.
+template <class T>
+__global__ void __launch_bounds__(256) count_negative_kernel(const T* __restrict__ x, long n,
+                                                             unsigned long long* __restrict__ partial) {
+    __shared__ double sh[4];
+    double c = 0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
+        c += (x[i] >= T(0)) ? 0.0 : 1.0;
+    double t = block_sum_256(c, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (unsigned long long)t;
+}
+
+// Column sums of a[rows, cols] over rows: stage 1 partial[b, c] over a row stripe,
+// stage 2 = reduce_slabs_kernel.  (KL denominators: grads.py:146,155.)
+template <class T>
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const T* __restrict__ a, long ld,
+                                                             long rows, long cols, long rows_per_blk,
+                                                             T* __restrict__ partial) {
+    const long r0 = blockIdx.y * rows_per_blk;
+    const long r1 = min(rows, r0 + rows_per_blk);
+    for (long c = blockIdx.x * 256L + threadIdx.x; c < cols; c += (long)gridDim.x * 256L) {
+        T acc = zero_of<T>();
+        for (long r = r0; r < r1; ++r) acc = add(acc, a[r * ld + c]);
+        partial[blockIdx.y * cols + c] = acc;
+    }
+}
+
+// Row sums of a[rows, cols]: one block per row.
+template <class T>
+__global__ void __launch_bounds__(256) rowsum_kernel(const T* __restrict__ a, long ld, long cols,
+                                                     T* __restrict__ out) {
+    __shared__ T sh[4];
+    const long row = blockIdx.x;
+    T acc = 0;
+    for (long j = threadIdx.x; j < cols; j += 256) acc += a[row * ld + j];
+    T t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) out[row] = t;
+}
+
+// sum of squares in double -> partial[block] (residual norm).
+template <class T>
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const T* __restrict__ a, long n,
+                                                            double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double c = 0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
+        c += (double)abs2(a[i]);
+    double t = block_sum_256(c, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+inline int grid_for(long n, int cap = 2048) {
+    long g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace dcp

@@ -1,0 +1,224 @@
+// C ABI: NMF multiplicative update (see include/decomp_hip.h for the contract and the
+// reference lines each entry point replaces).
+#include "nmf_impl.hpp"
+
+using namespace dcp;
+
+namespace {
+
+template <class T>
+int check_nmf_args(dcp_handle* h, const T* Y, const T* X, const T* D, int64_t N, int64_t F,
+                   int64_t K, int lik) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!Y || !X || !D) return fail(h, DCP_ERR_INVALID, "null array pointer");
+    if (N <= 0 || F <= 0 || K <= 0) return fail(h, DCP_ERR_INVALID, "sizes must be positive");
+    if (N > 0x7fffffffLL || F > 0x7fffffffLL || K > 0x7fffffffLL || F + K > 0x3fffffffLL)
+        return fail(h, DCP_ERR_INVALID, "dimension exceeds 2^31-1");
+    if (lik != DCP_LIK_L2 && lik != DCP_LIK_KL) return fail(h, DCP_ERR_INVALID, "bad likelihood");
+    return DCP_OK;
+}
+
+template <class T>
+int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N, int64_t F,
+                 int64_t K, int lik, T tol, int maxiter, int* it_out, T* last_maxdiff,
+                 T* resid_trace) {
+    DCP_TRY(check_nmf_args(h, Y, X, D, N, F, K, lik));
+    if (!it_out) return fail(h, DCP_ERR_INVALID, "it_out is null");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    const bool masked = mask != nullptr;
+    NmfShape<T> s{N, F, K, lik, masked};
+    const int64_t W = nmf_stats_width(F, K, lik, masked);
+    const bool want_resid = resid_trace != nullptr;
+    const bool gram = (lik == DCP_LIK_L2 && !masked);
+    const int resid_blocks = 1024;
+
+    WsPlan plan;
+    nmf_plan_stats(plan, s, masked);
+    nmf_plan_update<T>(plan, F, K);
+    plan.add<T>((size_t)K * W);   // stats
+    plan.add<T>((size_t)K * F);   // D_new
+    plan.add<T>(1);               // max|dD|
+    if (want_resid) {
+        if (gram) plan.add<T>((size_t)N * F);
+        plan.add<double>(resid_blocks);
+    }
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    NmfStatsWs<T> ws;
+    NmfUpdateWs<T> wu;
+    DCP_TRY(nmf_carve_stats(h, ws, s, masked));
+    DCP_TRY(nmf_carve_update(h, wu, F, K));
+    T* stats = ws_alloc<T>(h, (size_t)K * W);
+    T* Dnew = ws_alloc<T>(h, (size_t)K * F);
+    T* maxdiff_dev = ws_alloc<T>(h, 1);
+    T* resid_tmp = nullptr;
+    double* resid_part = nullptr;
+    if (want_resid) {
+        resid_tmp = gram ? ws_alloc<T>(h, (size_t)N * F) : ws.f;
+        resid_part = ws_alloc<double>(h, resid_blocks);
+    }
+    if (!stats || !Dnew || !maxdiff_dev || (want_resid && (!resid_tmp || !resid_part)))
+        return fail(h, DCP_ERR_INTERNAL, "nmf workspace plan mismatch");
+    void* hostv = nullptr;
+    DCP_TRY(host_scratch(h, sizeof(double) * (resid_blocks + 2), &hostv));
+    T* host_maxdiff = reinterpret_cast<T*>(hostv);
+    double* host_part = reinterpret_cast<double*>(hostv) + 1;
+
+    const T* Ypre = Y;
+    if (masked) {  // y * mask is loop invariant (grads.py:114,124 recompute it every call)
+        hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for(N * F)), dim3(256), 0, h->stream, Y,
+                           mask, (long)N, (long)F, (long)F, ws.Ym);
+        DCP_HIP_OK(h, hipGetLastError());
+        Ypre = ws.Ym;
+    }
+
+    T md = T(0);
+    for (int it = 1; it < maxiter; ++it) {  // batch_mu.py:16
+        DCP_TRY(nmf_stats<T>(h, Ypre, mask, X, D, s, stats, ws));
+        DCP_TRY(nmf_update<T>(h, stats, D, Dnew, F, K, lik, masked, maxdiff_dev, wu));
+        DCP_HIP_OK(h, hipMemcpyAsync(host_maxdiff, maxdiff_dev, sizeof(T), hipMemcpyDeviceToHost,
+                                     h->stream));
+        if (want_resid) {
+            DCP_TRY(nmf_residual<T>(h, Y, mask, X, Dnew, N, F, K, resid_tmp, resid_part,
+                                    resid_blocks));
+            DCP_HIP_OK(h, hipMemcpyAsync(host_part, resid_part, sizeof(double) * resid_blocks,
+                                         hipMemcpyDeviceToHost, h->stream));
+        }
+        // D <- D_new either way (on convergence the reference returns D_new, batch_mu.py:23)
+        DCP_HIP_OK(h, hipMemcpyAsync(D, Dnew, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice,
+                                     h->stream));
+        DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+        md = *host_maxdiff;
+        if (want_resid) {
+            double acc = 0.0;
+            for (int i = 0; i < resid_blocks; ++i) acc += host_part[i];
+            resid_trace[it - 1] = (T)sqrt(acc);
+        }
+        if (md < tol) {  // batch_mu.py:22 (a NaN compares false, as in NumPy)
+            *it_out = it;
+            if (last_maxdiff) *last_maxdiff = md;
+            return DCP_OK;
+        }
+    }
+    *it_out = maxiter;  // batch_mu.py:26
+    if (last_maxdiff) *last_maxdiff = md;
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    return DCP_OK;
+}
+
+template <class T>
+int nmf_mu_stats_api(dcp_handle* h, const T* Y, const T* mask, T* X, const T* D, int64_t N,
+                     int64_t F, int64_t K, int lik, T* stats) {
+    DCP_TRY(check_nmf_args(h, Y, X, D, N, F, K, lik));
+    if (!stats) return fail(h, DCP_ERR_INVALID, "stats is null");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    const bool masked = mask != nullptr;
+    NmfShape<T> s{N, F, K, lik, masked};
+    WsPlan plan;
+    nmf_plan_stats(plan, s, masked);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    NmfStatsWs<T> ws;
+    DCP_TRY(nmf_carve_stats(h, ws, s, masked));
+    const T* Ypre = Y;
+    if (masked) {
+        hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for(N * F)), dim3(256), 0, h->stream, Y,
+                           mask, (long)N, (long)F, (long)F, ws.Ym);
+        DCP_HIP_OK(h, hipGetLastError());
+        Ypre = ws.Ym;
+    }
+    return nmf_stats<T>(h, Ypre, mask, X, D, s, stats, ws);
+}
+
+template <class T>
+int nmf_mu_update_api(dcp_handle* h, const T* stats, const T* D, T* D_new, int64_t F, int64_t K,
+                      int lik, int masked, T* maxdiff_dev) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!stats || !D || !D_new || !maxdiff_dev) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (F <= 0 || K <= 0) return fail(h, DCP_ERR_INVALID, "sizes must be positive");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    // NOTE: shares the arena with dcp_nmf_mu_stats_*: the stats call's temporaries are dead
+    // by now (same stream), `stats` itself is caller memory.
+    WsPlan plan;
+    nmf_plan_update<T>(plan, F, K);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    NmfUpdateWs<T> wu;
+    DCP_TRY(nmf_carve_update(h, wu, F, K));
+    return nmf_update<T>(h, stats, D, D_new, F, K, lik, masked != 0, maxdiff_dev, wu);
+}
+
+template <class T>
+int nmf_residual_api(dcp_handle* h, const T* Y, const T* mask, const T* X, const T* D, int64_t N,
+                     int64_t F, int64_t K, double* out) {
+    DCP_TRY(check_nmf_args(h, Y, X, D, N, F, K, DCP_LIK_L2));
+    if (!out) return fail(h, DCP_ERR_INVALID, "out is null");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    const int blocks = 1024;
+    WsPlan plan;
+    plan.add<T>((size_t)N * F);
+    plan.add<double>(blocks);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    T* tmp = ws_alloc<T>(h, (size_t)N * F);
+    double* part = ws_alloc<double>(h, blocks);
+    if (!tmp || !part) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
+    void* hostv = nullptr;
+    DCP_TRY(host_scratch(h, sizeof(double) * blocks, &hostv));
+    DCP_TRY(nmf_residual<T>(h, Y, mask, X, D, N, F, K, tmp, part, blocks));
+    DCP_HIP_OK(h, hipMemcpyAsync(hostv, part, sizeof(double) * blocks, hipMemcpyDeviceToHost,
+                                 h->stream));
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    double acc = 0.0;
+    for (int i = 0; i < blocks; ++i) acc += reinterpret_cast<double*>(hostv)[i];
+    *out = sqrt(acc);
+    return DCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dcp_nmf_mu_stats_width(int64_t F, int64_t K, int likelihood, int masked) {
+    return nmf_stats_width(F, K, likelihood, masked != 0);
+}
+
+int dcp_nmf_mu_f32(dcp_handle* h, const float* Y, const float* mask, float* X, float* D, int64_t N,
+                   int64_t F, int64_t K, int likelihood, float tol, int maxiter, int* it_out,
+                   float* last_maxdiff, float* resid_trace) {
+    return nmf_mu_solve<float>(h, Y, mask, X, D, N, F, K, likelihood, tol, maxiter, it_out,
+                               last_maxdiff, resid_trace);
+}
+int dcp_nmf_mu_f64(dcp_handle* h, const double* Y, const double* mask, double* X, double* D,
+                   int64_t N, int64_t F, int64_t K, int likelihood, double tol, int maxiter,
+                   int* it_out, double* last_maxdiff, double* resid_trace) {
+    return nmf_mu_solve<double>(h, Y, mask, X, D, N, F, K, likelihood, tol, maxiter, it_out,
+                                last_maxdiff, resid_trace);
+}
+int dcp_nmf_mu_stats_f32(dcp_handle* h, const float* Y, const float* mask, float* X, const float* D,
+                         int64_t N, int64_t F, int64_t K, int likelihood, float* stats) {
+    return nmf_mu_stats_api<float>(h, Y, mask, X, D, N, F, K, likelihood, stats);
+}
+int dcp_nmf_mu_stats_f64(dcp_handle* h, const double* Y, const double* mask, double* X,
+                         const double* D, int64_t N, int64_t F, int64_t K, int likelihood,
+                         double* stats) {
+    return nmf_mu_stats_api<double>(h, Y, mask, X, D, N, F, K, likelihood, stats);
+}
+int dcp_nmf_mu_update_f32(dcp_handle* h, const float* stats, const float* D, float* D_new,
+                          int64_t F, int64_t K, int likelihood, int masked, float* maxdiff_dev) {
+    return nmf_mu_update_api<float>(h, stats, D, D_new, F, K, likelihood, masked, maxdiff_dev);
+}
+int dcp_nmf_mu_update_f64(dcp_handle* h, const double* stats, const double* D, double* D_new,
+                          int64_t F, int64_t K, int likelihood, int masked, double* maxdiff_dev) {
+    return nmf_mu_update_api<double>(h, stats, D, D_new, F, K, likelihood, masked, maxdiff_dev);
+}
+int dcp_nmf_residual_f32(dcp_handle* h, const float* Y, const float* mask, const float* X,
+                         const float* D, int64_t N, int64_t F, int64_t K, double* out) {
+    return nmf_residual_api<float>(h, Y, mask, X, D, N, F, K, out);
+}
+int dcp_nmf_residual_f64(dcp_handle* h, const double* Y, const double* mask, const double* X,
+                         const double* D, int64_t N, int64_t F, int64_t K, double* out) {
+    return nmf_residual_api<double>(h, Y, mask, X, D, N, F, K, out);
+}
+
+}  // extern "C"

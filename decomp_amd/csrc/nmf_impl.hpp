@@ -1,0 +1,300 @@
+// NMF multiplicative update on the device (templated on float / double).
+//
+// Reference path restated as kernels:
+//   decomp/nmf_methods/batch_mu.py:8-26     outer loop, stop rule
+//   decomp/nmf_methods/grads.py:77-93       x * max(pos,0) / max(neg,1e-15)
+//   decomp/nmf_methods/grads.py:108-125     Gaussian gradient parts
+//   decomp/nmf_methods/grads.py:143-160     Poisson gradient parts
+//   decomp/utils/normalize.py:13-21         l2_strict
+//
+// l2 without a mask uses the Gram formulation:
+//   (x D) D^T = x (D D^T)   and   x^T (x D) = (x^T x) D
+// which removes the [N,F] intermediate and 2/3 of the flops; masked and KL updates
+// cannot use it and keep the chained products with the [N,F] intermediate in HBM.
+//
+// One iteration =  stats(...)  [all-reduce of `stats` across ranks goes here]  update(...)
+#pragma once
+#include <math.h>
+
+#include "gemm.hpp"
+#include "handle.hpp"
+#include "kernels_small.hpp"
+
+namespace dcp {
+
+inline int64_t nmf_stats_width(int64_t F, int64_t K, int likelihood, bool masked) {
+    return (likelihood == DCP_LIK_L2 && !masked) ? (F + K) : 2 * F;
+}
+
+// Number of resident workgroup slots we size split-K grids for (4 WG/CU x 256 CUs).
+constexpr int kSplitTarget = 2048;
+constexpr int kMaxSplits = 64;
+
+template <class T>
+struct NmfShape {
+    int64_t N, F, K;
+    int lik;
+    bool masked;
+};
+
+// ---- workspace ---------------------------------------------------------------------
+template <class T>
+struct NmfStatsWs {
+    T* Q = nullptr;       // [N,K]   negative part of the x gradient
+    T* G = nullptr;       // [K,K]   D D^T (l2, no mask)
+    T* f = nullptr;       // [N,F]   (x D) o M  or  KL ratio
+    T* Ym = nullptr;      // [N,F]   Y o M when the caller did not pre-mask
+    T* slabs = nullptr;   // split-K partials
+    T* vecK = nullptr;    // [K]     KL: colsum(D) / colsum(x)
+    T* part = nullptr;    // column-sum partials
+    size_t slab_count = 0;
+};
+
+template <class T>
+inline size_t nmf_slab_elems(const NmfShape<T>& s) {
+    // the largest split-K product of the step: stats GEMM [K, W] (and G [K,K])
+    const int64_t W = nmf_stats_width(s.F, s.K, s.lik, s.masked);
+    GemmArgs<T> a;
+    a.M = (int)s.K; a.N = (int)W; a.K = (int)s.N;
+    plan_splits<FORM_TN>(a, kSplitTarget, kMaxSplits);
+    size_t stats_slabs = (size_t)a.ksplits * s.K * W;
+    GemmArgs<T> g;
+    g.M = (int)s.K; g.N = (int)s.K; g.K = (int)s.F;
+    plan_splits<FORM_NT>(g, kSplitTarget / 4, kMaxSplits);
+    size_t g_slabs = (size_t)g.ksplits * s.K * s.K;
+    return stats_slabs > g_slabs ? stats_slabs : g_slabs;
+}
+
+template <class T>
+inline void nmf_plan_stats(WsPlan& plan, const NmfShape<T>& s, bool need_ym) {
+    const bool gram = (s.lik == DCP_LIK_L2 && !s.masked);
+    plan.add<T>((size_t)s.N * s.K);                       // Q
+    if (gram) plan.add<T>((size_t)s.K * s.K);             // G
+    if (!gram) plan.add<T>((size_t)s.N * s.F);            // f
+    if (need_ym) plan.add<T>((size_t)s.N * s.F);          // Ym
+    plan.add<T>(nmf_slab_elems(s));                       // slabs
+    plan.add<T>((size_t)s.K);                             // vecK
+    plan.add<T>((size_t)64 * (s.K > s.F ? s.K : s.F));    // part
+}
+
+template <class T>
+inline int nmf_carve_stats(dcp_handle* h, NmfStatsWs<T>& w, const NmfShape<T>& s, bool need_ym) {
+    const bool gram = (s.lik == DCP_LIK_L2 && !s.masked);
+    w.Q = ws_alloc<T>(h, (size_t)s.N * s.K);
+    if (gram) w.G = ws_alloc<T>(h, (size_t)s.K * s.K);
+    if (!gram) w.f = ws_alloc<T>(h, (size_t)s.N * s.F);
+    if (need_ym) w.Ym = ws_alloc<T>(h, (size_t)s.N * s.F);
+    w.slab_count = nmf_slab_elems(s);
+    w.slabs = ws_alloc<T>(h, w.slab_count);
+    w.vecK = ws_alloc<T>(h, (size_t)s.K);
+    w.part = ws_alloc<T>(h, (size_t)64 * (s.K > s.F ? s.K : s.F));
+    if (!w.Q || !w.slabs || !w.vecK || !w.part || (gram && !w.G) || (!gram && !w.f) ||
+        (need_ym && !w.Ym))
+        return fail(h, DCP_ERR_INTERNAL, "nmf workspace plan mismatch");
+    return DCP_OK;
+}
+
+template <class T>
+struct NmfUpdateWs {
+    T* U = nullptr;        // [K,F] un-normalised new dictionary
+    T* rowmax = nullptr;   // [K]
+};
+template <class T>
+inline void nmf_plan_update(WsPlan& plan, int64_t F, int64_t K) {
+    plan.add<T>((size_t)K * F);
+    plan.add<T>((size_t)K);
+}
+template <class T>
+inline int nmf_carve_update(dcp_handle* h, NmfUpdateWs<T>& w, int64_t F, int64_t K) {
+    w.U = ws_alloc<T>(h, (size_t)K * F);
+    w.rowmax = ws_alloc<T>(h, (size_t)K);
+    if (!w.U || !w.rowmax) return fail(h, DCP_ERR_INTERNAL, "nmf workspace plan mismatch");
+    return DCP_OK;
+}
+
+#define DCP_LAUNCH_OK(h, what)                                                        \
+    do {                                                                              \
+        hipError_t _e = (what);                                                       \
+        if (_e != hipSuccess)                                                         \
+            return dcp::fail((h), DCP_ERR_HIP, std::string("launch failed: ") +       \
+                                                   hipGetErrorString(_e));            \
+    } while (0)
+
+// out[K] = column sums of a[rows, cols] (deterministic two-stage).
+template <class T>
+inline int column_sums(dcp_handle* h, const T* a, long ld, long rows, long cols, T* part, T* out) {
+    const int stripes = rows >= 64 ? 64 : (rows > 0 ? (int)rows : 1);
+    const long rows_per = (rows + stripes - 1) / stripes;
+    dim3 grid(grid_for(cols, 64), stripes);
+    hipLaunchKernelGGL((colsum_partial_kernel<T>), grid, dim3(256), 0, h->stream, a, ld, rows,
+                       cols, rows_per, part);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for(cols, 64)), dim3(256), 0, h->stream,
+                       part, cols, stripes, cols, out);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    return DCP_OK;
+}
+
+// ---- x update + local statistics ------------------------------------------------------
+// Ypre: Y already multiplied by the mask (or Y itself when there is no mask).
+template <class T>
+inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, T* X, const T* D,
+                     const NmfShape<T>& s, T* stats, NmfStatsWs<T>& w) {
+    hipStream_t st = h->stream;
+    const int N = (int)s.N, F = (int)s.F, K = (int)s.K;
+    const bool gram = (s.lik == DCP_LIK_L2 && !s.masked);
+    const int W = (int)nmf_stats_width(s.F, s.K, s.lik, s.masked);
+
+    // forward product x.D with an elementwise epilogue into the [N,F] intermediate w.f
+    auto forward = [&]() -> int {
+        ProfScope ps(h, DCP_PROF_FWD);
+        GemmArgs<T> fa;
+        fa.A = X; fa.lda = K; fa.B = D; fa.ldb = F; fa.M = N; fa.N = F; fa.K = K;
+        if (s.lik == DCP_LIK_L2)   // f = (x D) o M                 (grads.py:113,123)
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, fa, EpiMulMask<T>{mask, F, w.f, F})));
+        else                       // r = (Y o M) / (x D + eps)     (grads.py:145-149)
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, fa, EpiKlRatio<T>{Ypre, F, nullptr, 0, w.f, F})));
+        return DCP_OK;
+    };
+
+    // ---------------- x <- x * max(pos,0) / max(neg,eps) ----------------
+    const T* xnum_A = Ypre;   // left operand of the positive-part GEMM (. D^T)
+    const T* xden = w.Q;      // negative part
+    long ld_xden = K;
+    if (gram) {
+        {   // G = D D^T  (split over F, partial slabs summed in order)
+            ProfScope ps(h, DCP_PROF_GRAM);
+            GemmArgs<T> g;
+            g.A = D; g.lda = F; g.B = D; g.ldb = F; g.M = K; g.N = K; g.K = F;
+            plan_splits<FORM_NT>(g, kSplitTarget / 4, kMaxSplits);
+            DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, g, EpiSlab<T>{w.slabs, K, (long)K * K})));
+            hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * K)), dim3(256), 0,
+                               st, w.slabs, (long)K * K, g.ksplits, (long)K * K, w.G);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+        }
+        {   // Q = x G
+            ProfScope ps(h, DCP_PROF_XNEG);
+            GemmArgs<T> q;
+            q.A = X; q.lda = K; q.B = w.G; q.ldb = K; q.M = N; q.N = K; q.K = K;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, q, EpiStore<T>{w.Q, K})));
+        }
+    } else if (s.lik == DCP_LIK_L2) {
+        DCP_TRY(forward());
+        ProfScope ps(h, DCP_PROF_XNEG);   // Q = f D^T
+        GemmArgs<T> q;
+        q.A = w.f; q.lda = F; q.B = D; q.ldb = F; q.M = N; q.N = K; q.K = F;
+        DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, q, EpiStore<T>{w.Q, K})));
+    } else {
+        DCP_TRY(forward());
+        xnum_A = w.f;
+        ProfScope ps(h, DCP_PROF_XNEG);
+        if (!s.masked) {   // neg = colsum(D), one value per column of x (grads.py:146)
+            hipLaunchKernelGGL((rowsum_kernel<T>), dim3(K), dim3(256), 0, st, D, (long)F, (long)F,
+                               w.vecK);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+            xden = w.vecK;
+            ld_xden = 0;
+        } else {           // neg = M D^T (grads.py:150)
+            GemmArgs<T> q;
+            q.A = mask; q.lda = F; q.B = D; q.ldb = F; q.M = N; q.N = K; q.K = F;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, q, EpiStore<T>{w.Q, K})));
+        }
+    }
+    {   // x <- x * max(pos, 0) / max(neg, eps): quotient fused into the GEMM epilogue
+        ProfScope ps(h, DCP_PROF_XUPDATE);
+        GemmArgs<T> pg;
+        pg.A = xnum_A; pg.lda = F; pg.B = D; pg.ldb = F; pg.M = N; pg.N = K; pg.K = F;
+        DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, pg, EpiMuNum<T>{X, K, xden, ld_xden, X, K})));
+    }
+
+    // ---------------- local D-side sums with the NEW x ----------------
+    GemmArgs<T> sa;
+    sa.A = X; sa.lda = K; sa.M = K; sa.N = W; sa.K = N;
+    if (gram) {
+        sa.B = Ypre; sa.ldb = F; sa.B2 = X; sa.ldb2 = K; sa.n_b1 = F;      // [ x^T Y | x^T x ]
+    } else if (s.lik == DCP_LIK_L2) {
+        DCP_TRY(forward());
+        sa.B = Ypre; sa.ldb = F; sa.B2 = w.f; sa.ldb2 = F; sa.n_b1 = F;    // [ x^T Ym | x^T f ]
+    } else {
+        DCP_TRY(forward());
+        if (s.masked) {
+            sa.B = w.f; sa.ldb = F; sa.B2 = mask; sa.ldb2 = F; sa.n_b1 = F;  // [ x^T r | x^T M ]
+        } else {
+            sa.B = w.f; sa.ldb = F; sa.N = F;                               // x^T r only
+        }
+    }
+    const int Wg = sa.N;  // width produced by the GEMM (KL no-mask: F, the rest is filled below)
+    plan_splits<FORM_TN>(sa, kSplitTarget, kMaxSplits);
+    if ((size_t)sa.ksplits * K * Wg > w.slab_count)
+        return fail(h, DCP_ERR_INTERNAL, "nmf slab plan mismatch");
+    {
+        ProfScope ps(h, DCP_PROF_STATS);
+        DCP_LAUNCH_OK(h, (gemm<FORM_TN>(st, sa, EpiSlab<T>{w.slabs, Wg, (long)K * Wg})));
+    }
+    ProfScope ps(h, DCP_PROF_STATS_SUM);
+    if (Wg == W) {
+        hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * W)), dim3(256), 0, st,
+                           w.slabs, (long)K * W, sa.ksplits, (long)K * W, stats);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+    } else {
+        // KL without mask: numerator from the GEMM, denominator = colsum(x) broadcast over F
+        // (grads.py:155: x.T.sum(axis=1, keepdims=True)).  Summed over ranks like the rest.
+        hipLaunchKernelGGL((reduce_slabs_rows_kernel<T>), dim3(grid_for((long)K * F)), dim3(256), 0,
+                           st, w.slabs, (long)K * F, sa.ksplits, (long)K, (long)F, stats, (long)W);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        DCP_TRY(column_sums<T>(h, X, K, N, K, w.part, w.vecK));
+        hipLaunchKernelGGL((bcast_rows_kernel<T>), dim3(grid_for((long)K * F)), dim3(256), 0, st,
+                           w.vecK, (long)K, (long)F, stats + F, (long)W);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+    }
+    return DCP_OK;
+}
+
+// ---- D update from the (all-reduced) statistics ---------------------------------------
+template <class T>
+inline int nmf_update(dcp_handle* h, const T* stats, const T* D, T* D_new, int64_t F64, int64_t K64,
+                      int lik, bool masked, T* maxdiff_dev, NmfUpdateWs<T>& w) {
+    hipStream_t st = h->stream;
+    const int F = (int)F64, K = (int)K64;
+    const bool gram = (lik == DCP_LIK_L2 && !masked);
+    const int W = (int)nmf_stats_width(F64, K64, lik, masked);
+    {
+        ProfScope ps(h, DCP_PROF_DUPDATE);
+        if (gram) {
+            // U = D * max(x^T Y, 0) / max((x^T x) D, eps): quotient fused into the S.D GEMM
+            GemmArgs<T> a;
+            a.A = stats + F; a.lda = W; a.B = D; a.ldb = F; a.M = K; a.N = F; a.K = K;
+            a.tile = TILE_SMALL;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiMuDen<T>{D, F, stats, W, w.U, F})));
+        } else {
+            hipLaunchKernelGGL((mu_quotient_kernel<T>), dim3(grid_for((long)K * F)), dim3(256), 0,
+                               st, D, (long)F, stats, (long)W, stats + F, (long)W, 0, (long)K,
+                               (long)F, w.U, (long)F);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+        }
+    }
+    // D_new = l2_strict(U) ; max |D - D_new|
+    ProfScope ps(h, DCP_PROF_DNORM);
+    hipLaunchKernelGGL((row_normalize_kernel<T>), dim3(K), dim3(256), 0, st, w.U, (long)F, (long)F,
+                       1, D, (long)F, D_new, (long)F, w.rowmax);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    hipLaunchKernelGGL((final_max_kernel<T>), dim3(1), dim3(256), 0, st, w.rowmax, (long)K,
+                       maxdiff_dev);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    return DCP_OK;
+}
+
+// ---- residual ||(Y - X D) o M||_F ---------------------------------------------------------
+template <class T>
+inline int nmf_residual(dcp_handle* h, const T* Y, const T* mask, const T* X, const T* D, int64_t N,
+                        int64_t F, int64_t K, T* tmpNF, double* partial_dev, int nblocks) {
+    GemmArgs<T> a;
+    a.A = X; a.lda = K; a.B = D; a.ldb = F; a.M = (int)N; a.N = (int)F; a.K = (int)K;
+    DCP_LAUNCH_OK(h, (gemm<FORM_NN>(h->stream, a, EpiResidual<T>{Y, F, mask, F, tmpNF, F})));
+    hipLaunchKernelGGL((sumsq_partial_kernel<T>), dim3(nblocks), dim3(256), 0, h->stream, tmpNF,
+                       (long)N * F, partial_dev);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    return DCP_OK;
+}
+
+}  // namespace dcp

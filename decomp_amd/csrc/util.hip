@@ -1,0 +1,245 @@
+// C ABI: handle lifetime, row normalisation, sign scan, and the GEMM test hook.
+#include "gemm.hpp"
+#include "handle.hpp"
+#include "kernels_small.hpp"
+#include <new>
+
+#define DCP_STR2(x) #x
+#define DCP_STR(x) DCP_STR2(x)
+
+using namespace dcp;
+
+namespace {
+
+template <class T>
+int l2_normalize_api(dcp_handle* h, T* U, int64_t K, int64_t F, int strict) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!U) return fail(h, DCP_ERR_INVALID, "null array pointer");
+    if (K < 0 || F < 0) return fail(h, DCP_ERR_INVALID, "negative size");
+    if (K == 0 || F == 0) return DCP_OK;
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL((row_normalize_kernel<T>), dim3((unsigned)K), dim3(256), 0, h->stream,
+                       (const T*)U, (long)F, (long)F, strict, (const T*)nullptr, 0L, U, (long)F,
+                       (real_t<T>*)nullptr);
+    DCP_HIP_OK(h, hipGetLastError());
+    return DCP_OK;
+}
+
+template <class T>
+int count_negative_api(dcp_handle* h, const T* x, int64_t n, int64_t* count) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!count || (!x && n > 0)) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (n < 0) return fail(h, DCP_ERR_INVALID, "negative size");
+    *count = 0;
+    if (n == 0) return DCP_OK;
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    const int blocks = grid_for(n, 1024);
+    WsPlan plan;
+    plan.add<unsigned long long>(blocks);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    unsigned long long* part = ws_alloc<unsigned long long>(h, blocks);
+    if (!part) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
+    void* hostv = nullptr;
+    DCP_TRY(host_scratch(h, sizeof(unsigned long long) * blocks, &hostv));
+    hipLaunchKernelGGL((count_negative_kernel<T>), dim3(blocks), dim3(256), 0, h->stream, x,
+                       (long)n, part);
+    DCP_HIP_OK(h, hipGetLastError());
+    DCP_HIP_OK(h, hipMemcpyAsync(hostv, part, sizeof(unsigned long long) * blocks,
+                                 hipMemcpyDeviceToHost, h->stream));
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    unsigned long long tot = 0;
+    for (int i = 0; i < blocks; ++i) tot += reinterpret_cast<unsigned long long*>(hostv)[i];
+    *count = (int64_t)tot;
+    return DCP_OK;
+}
+
+// extra ("wide") tile shapes, reachable through the test hook for tuning sweeps
+typedef TileCfg<128, 256, 16, 64, 128, 2> CfgWideNT;
+typedef TileCfg<256, 128, 16, 128, 64, 2> CfgWideTN;
+
+template <int FORM, class T, class Epi>
+hipError_t gemm_hook_launch(hipStream_t st, const GemmArgs<T>& a, int tile, const Epi& epi) {
+    if constexpr (std::is_same<T, float>::value) {
+        if (tile == 3) {
+            GemmProblem p;
+            p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb;
+            p.B2 = nullptr; p.ldb2 = 0; p.n_b1 = a.N;
+            p.M = a.M; p.N = a.N; p.K = a.K; p.ksplits = a.ksplits; p.klen = a.klen;
+            p.tiles_m = p.tiles_n = 0;
+            p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
+            if (FORM == FORM_NT) return launch_gemm_mfma<CfgWideNT, KMAJOR, KMAJOR, Epi>(st, p, epi);
+            if (FORM == FORM_NN) return launch_gemm_mfma<CfgWideNT, KMAJOR, XMAJOR, Epi>(st, p, epi);
+            return launch_gemm_mfma<CfgWideTN, XMAJOR, XMAJOR, Epi>(st, p, epi);
+        }
+    }
+    return gemm<FORM>(st, a, epi);
+}
+
+template <class T>
+int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, int64_t N,
+             int64_t K, int ksplits, int tile) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!A || !B || !C) return fail(h, DCP_ERR_INVALID, "null array pointer");
+    if (M <= 0 || N <= 0 || K <= 0) return fail(h, DCP_ERR_INVALID, "sizes must be positive");
+    if (form < 0 || form > 2) return fail(h, DCP_ERR_INVALID, "bad form");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    GemmArgs<T> a;
+    a.A = A; a.B = B; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.lda = (form == FORM_TN) ? M : K;
+    a.ldb = (form == FORM_NT) ? K : N;
+    a.tile = (tile == 3) ? TILE_LARGE : tile;
+    hipError_t e = hipSuccess;
+    if (ksplits > 1) {
+        const long kblocks = (K + 15) / 16;
+        long s = ksplits > kblocks ? kblocks : ksplits;
+        a.klen = (int)(((kblocks + s - 1) / s) * 16);
+        a.ksplits = (int)((K + a.klen - 1) / a.klen);
+        WsPlan plan;
+        plan.add<T>((size_t)a.ksplits * M * N);
+        DCP_TRY(ws_reserve(h, plan.total));
+        ws_reset(h);
+        T* slabs = ws_alloc<T>(h, (size_t)a.ksplits * M * N);
+        if (!slabs) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
+        EpiSlab<T> epi{slabs, (long)N, (long)M * N};
+        if (form == FORM_NT) e = gemm_hook_launch<FORM_NT>(h->stream, a, tile, epi);
+        else if (form == FORM_NN) e = gemm_hook_launch<FORM_NN>(h->stream, a, tile, epi);
+        else e = gemm_hook_launch<FORM_TN>(h->stream, a, tile, epi);
+        if (e != hipSuccess) return fail(h, DCP_ERR_HIP, hipGetErrorString(e));
+        hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for(M * N)), dim3(256), 0, h->stream,
+                           slabs, (long)(M * N), a.ksplits, (long)(M * N), C);
+        DCP_HIP_OK(h, hipGetLastError());
+    } else {
+        EpiStore<T> epi{C, (long)N};
+        if (form == FORM_NT) e = gemm_hook_launch<FORM_NT>(h->stream, a, tile, epi);
+        else if (form == FORM_NN) e = gemm_hook_launch<FORM_NN>(h->stream, a, tile, epi);
+        else e = gemm_hook_launch<FORM_TN>(h->stream, a, tile, epi);
+        if (e != hipSuccess) return fail(h, DCP_ERR_HIP, hipGetErrorString(e));
+    }
+    return DCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcp_create(dcp_handle** out, int device) {
+    if (!out) return DCP_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return DCP_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return DCP_ERR_HIP;
+    dcp_handle* h = new (std::nothrow) dcp_handle();
+    if (!h) return DCP_ERR_NOMEM;
+    h->device = device;
+    *out = h;
+    return DCP_OK;
+}
+
+int dcp_destroy(dcp_handle* h) {
+    if (!h) return DCP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->arena) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipFree(h->arena);
+    }
+    if (h->host_pinned) (void)hipHostFree(h->host_pinned);
+    for (auto& r : h->prof_recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : h->prof_pool) (void)hipEventDestroy(e);
+    delete h;
+    return DCP_OK;
+}
+
+int dcp_set_stream(dcp_handle* h, void* hip_stream) {
+    if (!h) return DCP_ERR_INVALID;
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return DCP_OK;
+}
+
+int dcp_profile_enable(dcp_handle* h, int on) {
+    if (!h) return DCP_ERR_INVALID;
+    h->prof_on = on != 0;
+    return DCP_OK;
+}
+
+static int prof_fold(dcp_handle* h) {
+    if (h->prof_recs.empty()) return DCP_OK;
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    for (auto& r : h->prof_recs) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.label >= 0 &&
+            r.label < DCP_PROF_NLABELS) {
+            h->prof_ms[r.label] += ms;
+            h->prof_cnt[r.label] += 1;
+        }
+        h->prof_pool.push_back(r.a);
+        h->prof_pool.push_back(r.b);
+    }
+    h->prof_recs.clear();
+    return DCP_OK;
+}
+
+int dcp_profile_reset(dcp_handle* h) {
+    if (!h) return DCP_ERR_INVALID;
+    DCP_TRY(prof_fold(h));
+    for (int i = 0; i < DCP_PROF_NLABELS; ++i) {
+        h->prof_ms[i] = 0.0;
+        h->prof_cnt[i] = 0;
+    }
+    return DCP_OK;
+}
+
+int dcp_profile_read(dcp_handle* h, int label, double* total_ms, int64_t* count) {
+    if (!h) return DCP_ERR_INVALID;
+    if (label < 0 || label >= DCP_PROF_NLABELS || !total_ms || !count)
+        return fail(h, DCP_ERR_INVALID, "bad profile label or null output");
+    DCP_TRY(prof_fold(h));
+    *total_ms = h->prof_ms[label];
+    *count = h->prof_cnt[label];
+    return DCP_OK;
+}
+
+const char* dcp_profile_label_name(int label) {
+    static const char* names[DCP_PROF_NLABELS] = {"gram",  "x_neg",     "x_update", "forward", "stats",
+                                                  "stats_sum", "d_update", "d_norm",  "misc"};
+    return (label >= 0 && label < DCP_PROF_NLABELS) ? names[label] : "?";
+}
+
+const char* dcp_last_error_string(dcp_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+const char* dcp_build_info(void) {
+    return "libdecomp_hip: gfx950, fp32 MFMA 32x32x2 GEMM core, HIP " DCP_STR(HIP_VERSION_MAJOR) "." DCP_STR(HIP_VERSION_MINOR);
+}
+
+int dcp_l2_normalize_f32(dcp_handle* h, float* U, int64_t K, int64_t F, int strict) {
+    return l2_normalize_api<float>(h, U, K, F, strict);
+}
+int dcp_l2_normalize_f64(dcp_handle* h, double* U, int64_t K, int64_t F, int strict) {
+    return l2_normalize_api<double>(h, U, K, F, strict);
+}
+int dcp_l2_normalize_c64(dcp_handle* h, void* U, int64_t K, int64_t F, int strict) {
+    return l2_normalize_api<c64>(h, reinterpret_cast<c64*>(U), K, F, strict);
+}
+int dcp_l2_normalize_c128(dcp_handle* h, void* U, int64_t K, int64_t F, int strict) {
+    return l2_normalize_api<c128>(h, reinterpret_cast<c128*>(U), K, F, strict);
+}
+int dcp_count_negative_f32(dcp_handle* h, const float* x, int64_t n, int64_t* count) {
+    return count_negative_api<float>(h, x, n, count);
+}
+int dcp_count_negative_f64(dcp_handle* h, const double* x, int64_t n, int64_t* count) {
+    return count_negative_api<double>(h, x, n, count);
+}
+int dcp_gemm_f32(dcp_handle* h, int form, const float* A, const float* B, float* C, int64_t M,
+                 int64_t N, int64_t K, int ksplits, int tile) {
+    return gemm_api<float>(h, form, A, B, C, M, N, K, ksplits, tile);
+}
+int dcp_gemm_f64(dcp_handle* h, int form, const double* A, const double* B, double* C, int64_t M,
+                 int64_t N, int64_t K, int ksplits, int tile) {
+    return gemm_api<double>(h, form, A, B, C, M, N, K, ksplits, tile);
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""Non-negative matrix factorisation -- drop-in for ``decomp.nmf`` on MI355X.
+
+Same entry point, argument meaning, return convention and error behaviour as the
+reference's decomp/nmf.py:16-80 for the full-batch multiplicative-update path
+(``minibatch=None, method='mu'``).  The iteration itself
+(decomp/nmf_methods/batch_mu.py:8-26 with the update rules of
+decomp/nmf_methods/grads.py:77-160) runs in libdecomp_hip.so: see
+include/decomp_hip.h ``dcp_nmf_mu_*`` and decomp_amd/csrc/nmf_impl.hpp.
+"""
+import ctypes
+
+from . import _arrays, _hip
+from ._arrays import get_array_module
+from .utils import assertion
+
+BATCH_METHODS = ['mu']
+MINIBATCH_METHODS = [
+    'asg-mu', 'gsg-mu', 'asag-mu', 'gsag-mu',  # Serizel et al.
+    'svrmu', 'svrmu-acc',                      # Kasai et al.
+    ]
+_JITTER = 1.0e-15
+
+
+def _likelihood_code(likelihood):
+    """grads.py:7-14.  User-supplied Likelihood objects (grads.py:12-13) are a Python
+    plugin point of the reference that cannot run inside the HIP kernels."""
+    if likelihood in ('l2', 'gaussian'):
+        return _hip.LIK_L2
+    if likelihood in ('kl', 'poisson'):
+        return _hip.LIK_KL
+    raise NotImplementedError('Likelihood {} is not implemented for nmf'.format(likelihood))
+
+
+class _OnesLike(object):
+    """Stand-in for the default x = ones((N, K)) during validation, so that the default
+    is materialised directly in device memory."""
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), dtype
+
+
+def solve(y, D, x=None, tol=1.0e-3, minibatch=None, maxiter=1000, method='mu',
+          likelihood='l2', mask=None, random_seed=None, **kwargs):
+    """
+    Non-negative matrix factorisation  argmin_{x, D} |y - xD|^2,  x >= 0, D >= 0,
+    |D_j| = 1, by multiplicative updates.
+
+    y: [n_samples, n_channels], x: [n_samples, n_features], D: [n_features, n_channels],
+    mask (optional): [n_samples, n_channels], 0 marks a missing entry; float32 or
+    float64, all arrays of the same dtype.  NumPy arrays (copied to the GPU, results
+    returned as NumPy) or torch CUDA tensors (results returned as torch tensors).
+
+    Returns (it, D, x) exactly as the reference: ``it`` is the iteration at which
+    max|D - D_new| < tol was met, or ``maxiter`` when it never was.
+    """
+    kind = get_array_module(D)
+    x_given = x
+    if x is None:                                                     # nmf.py:53-54
+        x = _OnesLike((y.shape[0], D.shape[0]), _arrays.np_dtype(y))
+
+    assertion.assert_dtypes(y=y, D=D, x=x)                            # nmf.py:56-63
+    assertion.assert_dtypes(y=y, D=D, x=x, mask=mask, dtypes='f')
+    assertion.assert_shapes('x', x, 'D', D, axes=1)
+    assertion.assert_shapes('y', y, 'D', D, axes=[-1])
+    assertion.assert_shapes('y', y, 'mask', mask)
+    assertion.assert_ndim('y', y, 2)
+    assertion.assert_ndim('D', D, 2)
+    assertion.assert_ndim('x', x, 2)
+    get_array_module(D, x_given)
+
+    # ---- from here on everything lives on the GPU ----
+    import torch
+    D_dev = _arrays.to_device(D, copy=True)           # normalised in place below
+    dev = D_dev.device.index
+    if x_given is None:
+        x_dev = torch.ones(x.shape, dtype=D_dev.dtype, device=D_dev.device)
+    else:
+        x_dev = _arrays.to_device(x_given, dev, copy=True)   # updated in place
+    assertion.assert_nonnegative(D_dev)                               # nmf.py:64-65
+    assertion.assert_nonnegative(x_dev)
+    lik = None
+    if likelihood in ['kl']:                                          # nmf.py:67-68
+        y_dev = _arrays.to_device(y, dev)
+        assertion.assert_nonnegative(y_dev)
+    else:
+        y_dev = None
+
+    _arrays.l2_normalize_(D_dev, strict=True)                         # nmf.py:70
+
+    if minibatch is None:
+        get_array_module(y, D, x_given)                               # nmf.py:75
+        if method == 'mu':
+            if kwargs:  # batch_mu.solve accepts no extra keyword (nmf.py:77, batch_mu.py:8)
+                raise TypeError('solve() got an unexpected keyword argument %r'
+                                % sorted(kwargs)[0])
+            lik = _likelihood_code(likelihood)
+            if y_dev is None:
+                y_dev = _arrays.to_device(y, dev)
+            get_array_module(y, mask)
+            m_dev = _arrays.to_device(mask, dev)
+            it = _run_mu(y_dev, m_dev, x_dev, D_dev, lik, tol, maxiter)
+            return it, _arrays.to_caller(D_dev, kind), _arrays.to_caller(x_dev, kind)
+        raise NotImplementedError('Batch-NMF with {} algorithm is not yet '
+                                  'implemented.'.format(method))
+    # stochastic variants (serizel.py, kasai.py) are outside this build's hot path
+    raise NotImplementedError('NMF with {} algorithm (minibatch) is not implemented in '
+                              'decomp_amd: only the full-batch \'mu\' path is.'.format(method))
+
+
+def _run_mu(y, mask, x, D, lik, tol, maxiter, resid_trace=None):
+    """batch_mu.solve on device arrays; x and D are updated in place.  Returns it."""
+    lib, h = _arrays.lib_handle(D)
+    sfx = _arrays.suffix(D)
+    N, F = y.shape
+    K = D.shape[0]
+    ctype = ctypes.c_float if sfx == 'f32' else ctypes.c_double
+    it = ctypes.c_int(0)
+    last = ctype(0)
+    trace = None
+    if resid_trace is not None:
+        trace = (ctype * max(int(maxiter), 1))()
+    fn = getattr(lib, 'dcp_nmf_mu_' + sfx)
+    rc = fn(h, _arrays.ptr(y), _arrays.ptr(mask), _arrays.ptr(x), _arrays.ptr(D),
+            N, F, K, lik, ctype(tol), int(maxiter), ctypes.byref(it), ctypes.byref(last),
+            trace)
+    _hip.check(h, rc, 'dcp_nmf_mu_' + sfx)
+    if resid_trace is not None:
+        n_done = it.value if it.value < maxiter else maxiter - 1
+        resid_trace.extend(float(trace[i]) for i in range(max(n_done, 0)))
+    return it.value

@@ -1,0 +1,149 @@
+/*
+ * decomp_hip.h -- C ABI of libdecomp_hip.so, the MI355X (gfx950) implementation of
+ * deComP's iterative-update hot path.
+ *
+ * The reference (fujii-team/deComP) has no FFI: its "device layer" is the NumPy/CuPy
+ * array-module handle `xp` (decomp/utils/cp_compat.py:9-24) threaded through every
+ * solver.  This header is what replaces `xp` + the L1/L2 solver bodies for the hot
+ * path; each entry point cites the reference function it stands in for.  The
+ * reference-side binding (a ctypes stub) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: opaque handle, raw DEVICE pointers, sizes; no C++ or torch types.
+ *   - every function returns an int status (DCP_OK = 0, negative = error); no C++
+ *     exception crosses the ABI.  dcp_last_error_string() gives the message.
+ *   - arrays are C-contiguous row-major, exactly as the reference's NumPy arrays:
+ *       y[N,F]  x[N,K]  D[K,F]  mask[N,F]   (N samples, F features/channels, K atoms)
+ *   - dtype suffixes: f32, f64 (real), c64, c128 (interleaved re,im pairs).
+ *   - work is enqueued on the handle's stream (dcp_set_stream); functions that
+ *     return host scalars (iteration counts, max|dD|) synchronise that stream
+ *     before returning, the *_async step functions do not.
+ *   - a handle is bound to one device and is not re-entrant.
+ */
+#ifndef DECOMP_HIP_H
+#define DECOMP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dcp_handle dcp_handle;
+
+enum {
+    DCP_OK = 0,
+    DCP_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, bad enum) */
+    DCP_ERR_HIP = -2,       /* a HIP runtime call failed */
+    DCP_ERR_NOMEM = -3,     /* workspace allocation failed */
+    DCP_ERR_INTERNAL = -4,  /* library bug (workspace plan mismatch, ...) */
+    DCP_ERR_UNSUPPORTED = -5
+};
+
+/* likelihood codes: decomp/nmf_methods/grads.py:7-14 */
+enum { DCP_LIK_L2 = 0, DCP_LIK_KL = 1 };
+
+/* LASSO solver codes: decomp/lasso.py:13 (the starred subset of SURVEY 8a) */
+enum { DCP_LASSO_ISTA = 0, DCP_LASSO_ACC_ISTA = 1, DCP_LASSO_FISTA = 2, DCP_LASSO_CD = 3 };
+
+/* ---- lifetime ----------------------------------------------------------------- */
+int dcp_create(dcp_handle** out, int device);
+int dcp_destroy(dcp_handle* h);
+/* hipStream_t passed as void*; NULL = the device's default stream */
+int dcp_set_stream(dcp_handle* h, void* hip_stream);
+const char* dcp_last_error_string(dcp_handle* h);
+/* compile-time facts, for the loader's sanity check */
+const char* dcp_build_info(void);
+
+/* ---- per-kernel timing (measurement aid, used by bench.py) ---------------------- */
+/* While enabled, every labelled kernel group of the solvers is bracketed by hipEvents on
+ * the handle's stream.  dcp_profile_read synchronises the stream, folds the pending
+ * event pairs into per-label totals and returns total milliseconds and launch count. */
+enum {
+    DCP_PROF_GRAM = 0,        /* D D^T (split-K) + slab sum                      */
+    DCP_PROF_XNEG = 1,        /* negative part of the x gradient: x G, f D^T, M D^T */
+    DCP_PROF_XUPDATE = 2,     /* Y D^T GEMM with the fused MU quotient epilogue  */
+    DCP_PROF_FWD = 3,         /* (x D) o M / KL ratio: the [N,F] intermediate     */
+    DCP_PROF_STATS = 4,       /* x^T [Y | x] split-K GEMM                         */
+    DCP_PROF_STATS_SUM = 5,   /* slab sum of the statistics                       */
+    DCP_PROF_DUPDATE = 6,     /* (x^T x) D GEMM + quotient (or elementwise quotient) */
+    DCP_PROF_DNORM = 7,       /* l2_strict + max|dD|                              */
+    DCP_PROF_MISC = 8,
+    DCP_PROF_NLABELS = 9
+};
+int dcp_profile_enable(dcp_handle* h, int on);
+int dcp_profile_reset(dcp_handle* h);
+int dcp_profile_read(dcp_handle* h, int label, double* total_ms, int64_t* count);
+const char* dcp_profile_label_name(int label);
+
+/* ---- utilities ---------------------------------------------------------------- */
+/* utils/normalize.py:2-21.  Rows of U[K,F] divided by sqrt(sum|u|^2) (strict != 0)
+ * or by sqrt(max(sum|u|^2, 1)) (strict == 0), in place. */
+int dcp_l2_normalize_f32(dcp_handle* h, float* U, int64_t K, int64_t F, int strict);
+int dcp_l2_normalize_f64(dcp_handle* h, double* U, int64_t K, int64_t F, int strict);
+int dcp_l2_normalize_c64(dcp_handle* h, void* U, int64_t K, int64_t F, int strict);
+int dcp_l2_normalize_c128(dcp_handle* h, void* U, int64_t K, int64_t F, int strict);
+
+/* utils/assertion.py:95-100 (assert_nonnegative): number of elements for which
+ * `x >= 0` is false (negative values and NaNs), written to the HOST integer *count. */
+int dcp_count_negative_f32(dcp_handle* h, const float* x, int64_t n, int64_t* count);
+int dcp_count_negative_f64(dcp_handle* h, const double* x, int64_t n, int64_t* count);
+
+/* Test hook (not a reference interface): C[M,N] = op(A) . op(B) through the same GEMM
+ * cores the solvers use.  form: 0 = NT (A[M,K], B[N,K]), 1 = NN (A[M,K], B[K,N]),
+ * 2 = TN (A[K,M], B[K,N]).  ksplits >= 1 selects split-K (partials summed in order).
+ * tile: 0 = auto, 1 = large tile, 2 = small tile. */
+int dcp_gemm_f32(dcp_handle* h, int form, const float* A, const float* B, float* C,
+                 int64_t M, int64_t N, int64_t K, int ksplits, int tile);
+int dcp_gemm_f64(dcp_handle* h, int form, const double* A, const double* B, double* C,
+                 int64_t M, int64_t N, int64_t K, int ksplits, int tile);
+
+/* ---- NMF, multiplicative update ------------------------------------------------ */
+/* decomp/nmf_methods/batch_mu.py:8-26 (whole loop).  D must already be l2_strict
+ * normalised (nmf.py:70).  mask may be NULL.  On return X and D hold what the
+ * reference returns: (it, D_new, x) when max|D - D_new| < tol at iteration it,
+ * else (maxiter, D, x) after maxiter-1 iterations.  last_maxdiff (host, nullable)
+ * receives the last max|D - D_new|; resid_trace (host, nullable, length >= maxiter)
+ * receives ||(Y - X D_new) o mask||_F after every iteration (parity metric; costs one
+ * extra N.K.F product per iteration, so leave it NULL when timing). */
+int dcp_nmf_mu_f32(dcp_handle* h, const float* Y, const float* mask, float* X, float* D,
+                   int64_t N, int64_t F, int64_t K, int likelihood, float tol, int maxiter,
+                   int* it_out, float* last_maxdiff, float* resid_trace);
+int dcp_nmf_mu_f64(dcp_handle* h, const double* Y, const double* mask, double* X, double* D,
+                   int64_t N, int64_t F, int64_t K, int likelihood, double tol, int maxiter,
+                   int* it_out, double* last_maxdiff, double* resid_trace);
+
+/* One iteration split at the data-parallel exchange point, asynchronous:
+ *   dcp_nmf_mu_stats_*  : x <- update_x (grads.py:77-84), then this rank's share of
+ *                         the D-side sums (grads.py:117-125) into stats:
+ *                           l2, no mask : stats[K, F+K] = [ x^T Y | x^T x ]
+ *                           otherwise   : stats[K, 2F]  = [ numerator | denominator ]
+ *                         (the caller all-reduces stats over ranks: sums over rows)
+ *   dcp_nmf_mu_update_* : D_new <- l2_strict(D o max(num,0) / max(den,1e-15))
+ *                         (grads.py:86-93, batch_mu.py:21) written to D_new, and
+ *                         max|D - D_new| written to the DEVICE scalar maxdiff_dev.
+ * stats width: dcp_nmf_mu_stats_width(). */
+int64_t dcp_nmf_mu_stats_width(int64_t F, int64_t K, int likelihood, int masked);
+int dcp_nmf_mu_stats_f32(dcp_handle* h, const float* Y, const float* mask, float* X,
+                         const float* D, int64_t N, int64_t F, int64_t K, int likelihood,
+                         float* stats);
+int dcp_nmf_mu_stats_f64(dcp_handle* h, const double* Y, const double* mask, double* X,
+                         const double* D, int64_t N, int64_t F, int64_t K, int likelihood,
+                         double* stats);
+int dcp_nmf_mu_update_f32(dcp_handle* h, const float* stats, const float* D, float* D_new,
+                          int64_t F, int64_t K, int likelihood, int masked,
+                          float* maxdiff_dev);
+int dcp_nmf_mu_update_f64(dcp_handle* h, const double* stats, const double* D, double* D_new,
+                          int64_t F, int64_t K, int likelihood, int masked,
+                          double* maxdiff_dev);
+
+/* ||(Y - X D) o mask||_F (parity metric of SURVEY 8d; mask nullable). */
+int dcp_nmf_residual_f32(dcp_handle* h, const float* Y, const float* mask, const float* X,
+                         const float* D, int64_t N, int64_t F, int64_t K, double* out);
+int dcp_nmf_residual_f64(dcp_handle* h, const double* Y, const double* mask, const double* X,
+                         const double* D, int64_t N, int64_t F, int64_t K, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DECOMP_HIP_H */

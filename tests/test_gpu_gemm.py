@@ -1,0 +1,90 @@
+"""GPU: the GEMM cores behind every solver (fp32 MFMA, generic fp64) against NumPy
+float64, through the C ABI test hook dcp_gemm_*."""
+import numpy as np
+import pytest
+
+from gpu_util import gemm_hip, gemm_ref, gemm_bound
+
+pytestmark = pytest.mark.gpu
+
+
+def _operands(form, M, N, K, dtype, rng):
+    # asymmetric data: a swapped row/col map or a transposed operand cannot pass
+    if form == 0:
+        A, B = rng.randn(M, K), rng.randn(N, K)
+    elif form == 1:
+        A, B = rng.randn(M, K), rng.randn(K, N)
+    else:
+        A, B = rng.randn(K, M), rng.randn(K, N)
+    A = A + np.arange(A.shape[1])[None, :] * 0.01
+    B = B - np.arange(B.shape[0])[:, None] * 0.02
+    return A.astype(dtype), B.astype(dtype)
+
+
+SHAPES_ALIGNED = [(256, 256, 64), (512, 384, 4096), (128, 128, 16), (1024, 256, 512)]
+SHAPES_RAGGED = [(101, 20, 3), (37, 65, 129), (1, 1, 1), (3, 101, 20), (130, 258, 35),
+                 (257, 8, 4096)]
+
+
+@pytest.mark.parametrize('form', [0, 1, 2])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+def test_f32_aligned(form, tile):
+    rng = np.random.RandomState(form * 10 + tile)
+    for (M, N, K) in SHAPES_ALIGNED:
+        A, B = _operands(form, M, N, K, np.float32, rng)
+        C = gemm_hip(form, A, B, tile=tile)
+        err = np.abs(C - gemm_ref(form, A, B)) / gemm_bound(form, A, B)
+        assert err.max() < 2e-6, (form, tile, M, N, K, err.max())
+
+
+@pytest.mark.parametrize('form', [0, 1, 2])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+def test_f32_ragged(form, tile):
+    rng = np.random.RandomState(100 + form * 10 + tile)
+    for (M, N, K) in SHAPES_RAGGED:
+        A, B = _operands(form, M, N, K, np.float32, rng)
+        C = gemm_hip(form, A, B, tile=tile)
+        err = np.abs(C - gemm_ref(form, A, B)) / (gemm_bound(form, A, B) + 1e-30)
+        assert err.max() < 2e-6, (form, tile, M, N, K, err.max())
+
+
+@pytest.mark.parametrize('form', [0, 1, 2])
+@pytest.mark.parametrize('ksplits', [2, 5, 64])
+def test_f32_splitk(form, ksplits):
+    rng = np.random.RandomState(7 + ksplits)
+    for (M, N, K) in [(256, 128, 2048), (130, 70, 1000), (64, 64, 48)]:
+        for tile in (1, 2):
+            A, B = _operands(form, M, N, K, np.float32, rng)
+            C = gemm_hip(form, A, B, ksplits=ksplits, tile=tile)
+            err = np.abs(C - gemm_ref(form, A, B)) / gemm_bound(form, A, B)
+            assert err.max() < 2e-6, (form, ksplits, tile, M, N, K, err.max())
+
+
+def test_f32_identity_asymmetric():
+    """A = I with an asymmetric B catches a transposed C write (guide, section 3)."""
+    n = 128
+    B = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 251) - 100.0
+    I = np.eye(n, dtype=np.float32)
+    assert np.array_equal(gemm_hip(1, I, B, tile=1), B)       # NN: I . B
+    assert np.array_equal(gemm_hip(0, I, B, tile=1), B.T)     # NT: I . B^T
+    assert np.array_equal(gemm_hip(2, I, B, tile=1), B)       # TN: I^T . B
+    assert np.array_equal(gemm_hip(0, B, I, tile=1), B)       # NT: B . I^T
+
+
+def test_f32_bitwise_reproducible():
+    rng = np.random.RandomState(3)
+    A, B = _operands(2, 256, 384, 8192, np.float32, rng)
+    C1 = gemm_hip(2, A, B, ksplits=16, tile=1)
+    C2 = gemm_hip(2, A, B, ksplits=16, tile=1)
+    assert np.array_equal(C1, C2)
+
+
+@pytest.mark.parametrize('form', [0, 1, 2])
+def test_f64_generic(form):
+    rng = np.random.RandomState(11 + form)
+    for (M, N, K) in [(101, 20, 3), (256, 128, 8), (70, 130, 257), (64, 64, 64)]:
+        for ks in (1, 3):
+            A, B = _operands(form, M, N, K, np.float64, rng)
+            C = gemm_hip(form, A, B, ksplits=ks)
+            err = np.abs(C - gemm_ref(form, A, B)) / gemm_bound(form, A, B)
+            assert err.max() < 1e-14, (form, M, N, K, ks, err.max())

@@ -1,0 +1,143 @@
+"""GPU parity: decomp_amd.nmf (HIP, through the C ABI) against the CPU oracle and the
+golden vectors of the real reference."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _golden():
+    return np.load(os.path.join(GOLDEN, 'nmf_golden.npz'), allow_pickle=False)
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))) /
+                 max(1e-300, float(np.max(np.abs(b)))))
+
+
+def _trace_hip(y, D0, mask, lik, n):
+    """n iterations on the GPU with the per-iteration residual, via the product's own
+    host layer (tol = 0 never stops early)."""
+    import torch
+    from decomp_amd import _arrays, nmf as hnmf
+    yd = _arrays.to_device(y)
+    md = _arrays.to_device(mask)
+    Dd = _arrays.to_device(D0, copy=True)
+    _arrays.l2_normalize_(Dd, strict=True)
+    xd = torch.ones((y.shape[0], D0.shape[0]), dtype=yd.dtype, device='cuda')
+    trace = []
+    it = hnmf._run_mu(yd, md, xd, Dd, hnmf._likelihood_code(lik), 0.0, n + 1, resid_trace=trace)
+    assert it == n + 1
+    return Dd.cpu().numpy(), xd.cpu().numpy(), np.array(trace)
+
+
+@pytest.mark.parametrize('case', [
+    'nmf_64x48k4', 'nmf_101x20k3', 'nmf_256x128k8'])
+@pytest.mark.parametrize('dt', ['float64', 'float32'])
+@pytest.mark.parametrize('lik', ['l2', 'kl'])
+@pytest.mark.parametrize('mtag', ['nomask', 'mask'])
+def test_trace_matches_reference(case, dt, lik, mtag):
+    """25 iterations: per-iteration residual within 1e-5 rel (fp32) / 1e-10 (fp64) of the
+    reference's own trace; final x, D likewise."""
+    g = _golden()
+    base = '%s_%s_%s' % (case, dt, lik)
+    name = base + '_' + mtag
+    y, D0 = g[base + '/y'], g[base + '/D0']
+    mask = g[base + '/mask'] if mtag == 'mask' else None
+    ref_res = g[name + '/trace_resid']
+    D, x, res = _trace_hip(y, D0, mask, lik, len(ref_res))
+    tol = 1e-5 if dt == 'float32' else 1e-10
+    assert len(res) == len(ref_res)
+    assert np.max(np.abs(res - ref_res) / ref_res) < tol, np.max(np.abs(res - ref_res) / ref_res)
+    xt = 2e-4 if dt == 'float32' else 1e-9
+    assert _rel(D, g[name + '/trace_D']) < xt
+    assert _rel(x, g[name + '/trace_x']) < xt
+    assert D.dtype == y.dtype and x.dtype == y.dtype
+
+
+@pytest.mark.parametrize('dt', ['float64', 'float32'])
+@pytest.mark.parametrize('lik', ['l2', 'kl'])
+@pytest.mark.parametrize('mtag', ['nomask', 'mask'])
+def test_public_solve_matches_reference(dt, lik, mtag):
+    """decomp_amd.nmf.solve end to end on the reference test's own shape
+    (tests/test_nmf.py:59-102): same iteration count (fp64) and same solution."""
+    import decomp_amd
+    g = _golden()
+    base = 'nmf_101x20k3_%s_%s' % (dt, lik)
+    name = base + '_' + mtag
+    y, D0 = g[base + '/y'], g[base + '/D0']
+    mask = g[base + '/mask'] if mtag == 'mask' else None
+    it, D, x = decomp_amd.nmf.solve(y, D0.copy(), x=None, tol=float(g[name + '/tol']),
+                                    maxiter=400, method='mu', likelihood=lik, mask=mask,
+                                    random_seed=0)
+    assert isinstance(D, np.ndarray) and D.dtype == y.dtype
+    if dt == 'float64':
+        assert it == int(g[name + '/it'])
+        assert _rel(D, g[name + '/D']) < 1e-9 and _rel(x, g[name + '/x']) < 1e-9
+    else:
+        assert abs(it - int(g[name + '/it'])) <= 3
+        assert _rel(D, g[name + '/D']) < 5e-4 and _rel(x, g[name + '/x']) < 5e-4
+
+
+def test_against_oracle_medium_fp32():
+    """8192 x 1024, k = 64 (SURVEY 8d parity gate): 20 iterations, residual per
+    iteration within 1e-5 rel of the CPU oracle."""
+    from oracle import nmf as onmf, common
+    rng = np.random.RandomState(0)
+    N, F, K = 8192, 1024, 64
+    xt = np.maximum(rng.randn(N, K), 0).astype(np.float32)
+    Dt = np.maximum(rng.randn(K, F), 0).astype(np.float32)
+    y = (xt @ Dt + 0.1 * np.abs(rng.randn(N, F))).astype(np.float32)
+    D0 = np.maximum(Dt + 0.3 * rng.randn(K, F), 0.1).astype(np.float32)
+    n = 20
+    D, x, res = _trace_hip(y, D0, None, 'l2', n)
+    Do = common.l2_strict(D0)
+    xo = np.ones((N, K), np.float32)
+    for i in range(n):
+        xo, Do, _ = onmf.mu_step(y, xo, Do)
+        ro = onmf.residual(y, xo, Do)
+        assert abs(res[i] - ro) / ro < 1e-5, (i, res[i], ro)
+    assert _rel(D, Do) < 1e-3 and _rel(x, xo) < 1e-3
+
+
+def test_masked_entries_contribute_exactly_zero():
+    """Values under the mask must not influence anything: flip them to garbage and
+    require bit-identical outputs."""
+    import decomp_amd
+    rng = np.random.RandomState(1)
+    N, F, K = 300, 96, 5
+    y = np.abs(rng.randn(N, F)).astype(np.float32)
+    D0 = np.abs(rng.randn(K, F)).astype(np.float32) + 0.1
+    mask = (rng.uniform(size=(N, F)) >= 0.2).astype(np.float32)
+    y2 = y.copy()
+    y2[mask == 0] = 1.0e3 * rng.rand(int((mask == 0).sum())).astype(np.float32)
+    for lik in ('l2', 'kl'):
+        a = decomp_amd.nmf.solve(y, D0.copy(), tol=0.0, maxiter=12, likelihood=lik, mask=mask)
+        b = decomp_amd.nmf.solve(y2, D0.copy(), tol=0.0, maxiter=12, likelihood=lik, mask=mask)
+        assert a[0] == b[0] == 12
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_torch_tensors_in_place_semantics_and_errors():
+    import torch
+    import decomp_amd
+    rng = np.random.RandomState(2)
+    y = torch.from_numpy(np.abs(rng.randn(64, 32)).astype(np.float32)).cuda()
+    D0 = torch.from_numpy(np.abs(rng.randn(4, 32)).astype(np.float32) + 0.1).cuda()
+    D0_copy = D0.clone()
+    it, D, x = decomp_amd.nmf.solve(y, D0, tol=1e-3, maxiter=50)
+    assert isinstance(D, torch.Tensor) and D.is_cuda and x.shape == (64, 4)
+    assert torch.equal(D0, D0_copy)          # inputs are not mutated
+    # negative D -> AssertionError (assertion.py:99-100)
+    Dneg = D0.clone(); Dneg[0, 0] = -1.0
+    with pytest.raises(AssertionError):
+        decomp_amd.nmf.solve(y, Dneg)
+    # mixing array kinds -> TypeError (cp_compat.py:13)
+    with pytest.raises(TypeError):
+        decomp_amd.nmf.solve(y.cpu().numpy(), D0)
+    with pytest.raises(NotImplementedError):
+        decomp_amd.nmf.solve(y, D0, method='nope')

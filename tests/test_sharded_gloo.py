@@ -1,0 +1,106 @@
+"""CPU, world_size 2 over gloo: the host logic of the row-sharded MU loop
+(decomp_amd.sharded.mu_loop: shard rows, ONE all-reduce of the [K, F+K] statistics per
+iteration, replicated D update and stop test).  The per-rank arithmetic, which on a GPU
+box is the HIP library, is supplied here by the CPU oracle acting as a stand-in backend --
+this tests the partitioning/collective logic, not the kernels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleStepBackend(object):
+    """Same interface as decomp_amd.sharded.HipStepBackend, arithmetic by the oracle."""
+
+    def __init__(self, y, mask, x, lik):
+        from oracle import nmf as onmf
+        self.o = onmf
+        self.y, self.mask, self.x, self.lik = y, mask, x, lik
+        self.md = [0.0, 0.0]
+
+    def local_stats(self, D):
+        Dn = D.numpy()
+        self.x[...] = self.o.update_x(self.y, self.x, Dn, self.mask, self.lik)
+        pos, neg = self.o._parts_d(self.y, self.x, Dn, self.mask, self.lik)
+        if self.lik == 'l2' and self.mask is None:
+            stats = np.concatenate([self.x.T @ self.y, self.x.T @ self.x], axis=1)
+        else:
+            stats = np.concatenate([pos, np.broadcast_to(neg, pos.shape)], axis=1)
+        return torch.from_numpy(np.ascontiguousarray(stats))
+
+    def update(self, stats, D, D_new, slot):
+        from oracle.common import l2_strict
+        s, Dn = stats.numpy(), D.numpy()
+        F = Dn.shape[1]
+        if self.lik == 'l2' and self.mask is None:
+            num, den = s[:, :F], s[:, F:] @ Dn
+        else:
+            num, den = s[:, :F], s[:, F:]
+        out = l2_strict(Dn * np.maximum(num, 0) / np.maximum(den, 1e-15))
+        self.md[slot] = float(np.max(np.abs(Dn - out)))
+        D_new.copy_(torch.from_numpy(out))
+
+    def read_maxdiff(self, slot):
+        return self.md[slot]
+
+
+def _problem(lik, masked):
+    rng = np.random.RandomState(5)
+    N, F, K = 96, 20, 3
+    xt, Dt = np.maximum(rng.randn(N, K), 0), np.maximum(rng.randn(K, F), 0)
+    y = xt @ Dt + 0.1 * np.abs(rng.randn(N, F))
+    D0 = np.maximum(Dt + 0.3 * rng.randn(K, F), 0.1)
+    mask = np.rint(rng.uniform(0.3, 1, size=(N, F))) if masked else None
+    return y, D0, mask
+
+
+def _worker(rank, world, port, lik, masked, tol, maxiter, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from decomp_amd import sharded
+        from oracle.common import l2_strict
+        y, D0, mask = _problem(lik, masked)
+        rows = slice(rank * len(y) // world, (rank + 1) * len(y) // world)
+        x = np.ones((rows.stop - rows.start, D0.shape[0]))
+        be = OracleStepBackend(y[rows], None if mask is None else mask[rows], x, lik)
+        D = torch.from_numpy(l2_strict(D0))
+        it, Dout = sharded.mu_loop(be, D, tol, maxiter, world_size=world,
+                                   new_like=torch.empty_like)
+        q.put((rank, it, Dout.numpy().copy(), x.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('lik,masked', [('l2', False), ('l2', True), ('kl', False), ('kl', True)])
+def test_two_rank_sharded_loop_equals_single_process(lik, masked):
+    from oracle import nmf as onmf
+    world, tol, maxiter = 2, 1e-5, 120
+    y, D0, mask = _problem(lik, masked)
+    it_ref, D_ref, x_ref = onmf.solve(y, D0.copy(), tol=tol, maxiter=maxiter, likelihood=lik,
+                                      mask=mask)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lik, masked, tol, maxiter, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    its = [r[1] for r in res]
+    assert its[0] == its[1] == it_ref                 # identical decision on every rank
+    assert np.array_equal(res[0][2], res[1][2])        # replicated D is bit-identical
+    assert np.allclose(res[0][2], D_ref, rtol=1e-9, atol=1e-12)
+    x_all = np.concatenate([r[3] for r in res], axis=0)
+    assert np.allclose(x_all, x_ref, rtol=1e-8, atol=1e-12)
