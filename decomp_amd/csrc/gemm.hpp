@@ -67,7 +67,8 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits) {
         bm = L::BM;
         bn = L::BN;
     }
-    const long tiles = (long)ceil_div(a.M, bm) * ceil_div(a.N, bn);
+    const int n1 = a.B2 != nullptr ? a.n_b1 : a.N;
+    const long tiles = (long)ceil_div(a.M, bm) * (ceil_div(n1, bn) + ceil_div(a.N - n1, bn));
     long s = tiles > 0 ? target_wgs / tiles : 1;  // floor: stay within `target` resident slots
     if (s > max_splits) s = max_splits;
     const long kblocks = ceil_div(a.K > 0 ? a.K : 1, 16);

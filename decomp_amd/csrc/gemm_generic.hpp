@@ -25,6 +25,7 @@ struct GenericProblem {
     int M, N, K;
     int ksplits, klen;
     int tiles_m, tiles_n;
+    int tiles_n1;  // n tiles of the first B segment (tiles never straddle the seam)
 };
 
 template <class T, bool CONJA, bool CONJB, class Epi>
@@ -38,19 +39,21 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(GenericProblem<T> p, 
     const int split = blockIdx.x / tiles;
     const int t = blockIdx.x - split * tiles;
     const int mt = t % p.tiles_m, nt = t / p.tiles_m;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = mt * BM;
     const int kbeg = split * p.klen;
     const int kend = min(p.K, kbeg + p.klen);
 
     const T* Bp = p.B;
     long sBk = p.sBk, sBn = p.sBn;
-    int nB0 = n0, nBlim = p.n_b1;
-    if (p.B2 != nullptr && n0 >= p.n_b1) {
+    int nB0 = nt * BN, nBlim = p.n_b1, n0 = nB0, ncol_end = p.n_b1;
+    if (nt >= p.tiles_n1) {
         Bp = p.B2;
         sBk = p.sB2k;
         sBn = p.sB2n;
-        nB0 = n0 - p.n_b1;
+        nB0 = (nt - p.tiles_n1) * BN;
         nBlim = p.N - p.n_b1;
+        n0 = p.n_b1 + nB0;
+        ncol_end = p.N;
     }
 
     T acc[4][4];
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(GenericProblem<T> p, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + tx + 16 * j;
-            if (row < p.M && col < p.N) epi(row, col, acc[i][j], split);
+            if (row < p.M && col < ncol_end) epi(row, col, acc[i][j], split);
         }
     }
 }
@@ -107,11 +110,12 @@ __global__ void __launch_bounds__(256) gemm_generic_kernel(GenericProblem<T> p, 
 template <class T, class Epi>
 inline hipError_t launch_gemm_generic(hipStream_t stream, GenericProblem<T> p, bool conjA,
                                       bool conjB, const Epi& epi) {
+    if (p.B2 == nullptr) p.n_b1 = p.N;
     p.tiles_m = (p.M + 63) / 64;
-    p.tiles_n = (p.N + 63) / 64;
+    p.tiles_n1 = (p.n_b1 + 63) / 64;
+    p.tiles_n = p.tiles_n1 + (p.N - p.n_b1 + 63) / 64;
     if (p.ksplits < 1) p.ksplits = 1;
     if (p.ksplits == 1) p.klen = p.K > 0 ? p.K : 1;
-    if (p.B2 == nullptr) p.n_b1 = p.N;
     const int grid = p.tiles_m * p.tiles_n * p.ksplits;
     if (grid <= 0) return hipSuccess;
     if (conjA && conjB)

@@ -50,7 +50,8 @@ struct GemmProblem {
     int M, N, K;
     int ksplits, klen;
     int tiles_m, tiles_n;
-    int mt_fast;  // 1: consecutive logical ids walk m tiles first
+    int tiles_n1;  // n tiles that belong to the first B segment (tiles never straddle)
+    int mt_fast;   // 1: consecutive logical ids walk m tiles first
 };
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_>
@@ -178,19 +179,25 @@ __global__ void __launch_bounds__(256, Cfg::MINW) gemm_mfma_kernel(GemmProblem p
         nt = t % p.tiles_n;
         mt = t / p.tiles_n;
     }
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = mt * BM;
     const int kbeg = split * p.klen;
     const int kend = min(p.K, kbeg + p.klen);
 
-    // B may be two column segments laid side by side ([Y | x] in the TN stats GEMM)
+    // B may be two column segments laid side by side ([Y | x] in the TN stats GEMM).
+    // Each segment has its own run of n tiles, so a tile never straddles the seam.
     const float* Bp = p.B;
     long ldb = p.ldb;
-    int nB0 = n0, nBrows = p.n_b1;
-    if (p.B2 != nullptr && n0 >= p.n_b1) {
+    int nB0 = nt * BN;       // first row (= output column) of this tile inside its segment
+    int nBrows = p.n_b1;     // rows of that segment
+    int n0 = nB0;            // first output column
+    int ncol_end = p.n_b1;   // output columns this tile may write: [n0, ncol_end)
+    if (nt >= p.tiles_n1) {
         Bp = p.B2;
         ldb = p.ldb2;
-        nB0 = n0 - p.n_b1;
+        nB0 = (nt - p.tiles_n1) * BN;
         nBrows = p.N - p.n_b1;
+        n0 = p.n_b1 + nB0;
+        ncol_end = p.N;
     }
 
     f32x16 acc[TM][TN];
@@ -257,7 +264,7 @@ __global__ void __launch_bounds__(256, Cfg::MINW) gemm_mfma_kernel(GemmProblem p
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (!EDGE || (row < p.M && col < p.N)) epi(row, col, acc[i][j][r], split);
+                if (!EDGE || (row < p.M && col < ncol_end)) epi(row, col, acc[i][j][r], split);
             }
         }
     }
@@ -267,8 +274,10 @@ __global__ void __launch_bounds__(256, Cfg::MINW) gemm_mfma_kernel(GemmProblem p
 template <class Cfg, int ALAY, int BLAY, class Epi>
 inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi& epi) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+    if (p.B2 == nullptr) p.n_b1 = p.N;
     p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
+    p.tiles_n1 = (p.n_b1 + BN - 1) / BN;
+    p.tiles_n = p.tiles_n1 + (p.N - p.n_b1 + BN - 1) / BN;
     if (p.ksplits < 1) p.ksplits = 1;
     if (p.ksplits == 1) {
         p.klen = ((p.K + BK - 1) / BK) * BK;
@@ -278,10 +287,7 @@ inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi&
     // every split range [s*klen, min(K, (s+1)*klen)) is then a whole number of K blocks
     bool fast = (p.M % BM == 0) && (p.N % BN == 0) && (p.K % BK == 0) && (p.klen % BK == 0) &&
                 (p.lda % 4 == 0) && (p.ldb % 4 == 0) && al16(p.A) && al16(p.B) && p.K > 0;
-    if (p.B2 != nullptr)
-        fast = fast && (p.n_b1 % BN == 0) && (p.ldb2 % 4 == 0) && al16(p.B2);
-    else
-        p.n_b1 = p.N;
+    if (p.B2 != nullptr) fast = fast && (p.n_b1 % BN == 0) && (p.ldb2 % 4 == 0) && al16(p.B2);
     const int grid = p.tiles_m * p.tiles_n * p.ksplits;
     if (grid <= 0) return hipSuccess;
     if (fast)

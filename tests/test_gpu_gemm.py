@@ -34,7 +34,7 @@ def test_f32_aligned(form, tile):
         A, B = _operands(form, M, N, K, np.float32, rng)
         C = gemm_hip(form, A, B, tile=tile)
         err = np.abs(C - gemm_ref(form, A, B)) / gemm_bound(form, A, B)
-        assert err.max() < 2e-6, (form, tile, M, N, K, err.max())
+        assert err.max() < 2e-5, (form, tile, M, N, K, err.max())
 
 
 @pytest.mark.parametrize('form', [0, 1, 2])
@@ -45,7 +45,7 @@ def test_f32_ragged(form, tile):
         A, B = _operands(form, M, N, K, np.float32, rng)
         C = gemm_hip(form, A, B, tile=tile)
         err = np.abs(C - gemm_ref(form, A, B)) / (gemm_bound(form, A, B) + 1e-30)
-        assert err.max() < 2e-6, (form, tile, M, N, K, err.max())
+        assert err.max() < 2e-5, (form, tile, M, N, K, err.max())
 
 
 @pytest.mark.parametrize('form', [0, 1, 2])
@@ -57,7 +57,7 @@ def test_f32_splitk(form, ksplits):
             A, B = _operands(form, M, N, K, np.float32, rng)
             C = gemm_hip(form, A, B, ksplits=ksplits, tile=tile)
             err = np.abs(C - gemm_ref(form, A, B)) / gemm_bound(form, A, B)
-            assert err.max() < 2e-6, (form, ksplits, tile, M, N, K, err.max())
+            assert err.max() < 2e-5, (form, ksplits, tile, M, N, K, err.max())
 
 
 def test_f32_identity_asymmetric():
