@@ -49,12 +49,16 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // Tile footprint the float path will use for this problem (needed to plan split-K
 // before the launch).  Large tiles when they alone give the chip enough workgroups.
 template <int FORM>
-inline bool use_small_tile(int M, int N, int tile_sel) {
+inline bool use_small_tile(int M, int N, int K, int tile_sel) {
     if (tile_sel == TILE_LARGE) return false;
     if (tile_sel == TILE_SMALL) return true;
     typedef typename LargeCfgOf<FORM>::type L;
     const long wgs_large = (long)ceil_div(M, L::BM) * ceil_div(N, L::BN);
-    return wgs_large < 96;
+    // a deep reduction can still fill the chip with large tiles through split-K
+    long splits = K / 512;
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    return wgs_large * splits < 256;
 }
 
 // Choose split-K so that the grid reaches ~target workgroups, each split a multiple
@@ -62,7 +66,7 @@ inline bool use_small_tile(int M, int N, int tile_sel) {
 template <int FORM, class T>
 inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits) {
     int bm = 64, bn = 64;
-    if (std::is_same<T, float>::value && !use_small_tile<FORM>(a.M, a.N, a.tile)) {
+    if (std::is_same<T, float>::value && !use_small_tile<FORM>(a.M, a.N, a.K, a.tile)) {
         typedef typename LargeCfgOf<FORM>::type L;
         bm = L::BM;
         bn = L::BN;
@@ -93,7 +97,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
         constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
         constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
-        if (use_small_tile<FORM>(a.M, a.N, a.tile))
+        if (use_small_tile<FORM>(a.M, a.N, a.K, a.tile))
             return launch_gemm_mfma<CfgSmall, AL, BL, Epi>(stream, p, epi);
         return launch_gemm_mfma<typename LargeCfgOf<FORM>::type, AL, BL, Epi>(stream, p, epi);
     } else {

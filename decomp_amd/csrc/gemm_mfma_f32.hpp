@@ -17,9 +17,12 @@
 //   TN  (A XMAJOR, B XMAJOR):  x^T . Y,  x^T . x   (reduction over samples)
 //
 // LDS images:
-//   KMAJOR panel: [rows][BK + 4] floats.  Each lane fetches 4 consecutive k of
-//     its row with one ds_read_b128; the +4 pad makes the 16-lane b128 groups
-//     hit 16 distinct 4-bank slots (row stride 20 dwords -> 5r mod 16 distinct).
+//   KMAJOR panel: [rows][BK] floats, no padding, 16-byte chunks XOR-swizzled:
+//     chunk q of row r lives at chunk q ^ ((r / R) % C), C = BK/4 chunks per row,
+//     R = 64/BK rows per 256-byte bank row.  Each lane fetches 4 consecutive k of
+//     its row with one ds_read_b128; the 16 rows of a b128 lane group then hit 16
+//     distinct 4-bank slots (conflict free), and a 128x128 tile pair needs 32 KiB
+//     so four workgroups fit a CU's 160 KiB.
 //   XMAJOR panel: [BK][rows] floats, read with ds_read_b32 (32 consecutive
 //     dwords per half wave: conflict free).
 // k order inside a K block: the lane half h = lane >> 5 of MFMA step (c, j)
@@ -71,7 +74,14 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 
 template <int LAY, int ROWS, int BK>
 struct PanelGeom {
-    static constexpr int STRIDE = (LAY == KMAJOR) ? (BK + 4) : ROWS;
+    static constexpr int STRIDE = (LAY == KMAJOR) ? BK : ROWS;
+    static constexpr int CHUNKS = BK / 4;   // 16-byte chunks per KMAJOR row
+    static constexpr int RPB = 64 / BK;     // KMAJOR rows per 256-byte bank row
+    static_assert(BK <= 64 && 64 % BK == 0, "BK must divide 64");
+    // float offset of chunk q (4 floats) of row r in the swizzled KMAJOR image
+    __device__ static __forceinline__ int kchunk(int r, int q) {
+        return r * BK + ((q ^ ((r / RPB) % CHUNKS)) << 2);
+    }
     static constexpr int LINES = (LAY == KMAJOR) ? ROWS : BK;
     static constexpr int ELEMS = STRIDE * LINES;
     static constexpr int F4 = ROWS * BK / 4 / 256;  // float4 per thread per block
@@ -121,8 +131,8 @@ __device__ __forceinline__ void panel_lds_store(float* s, const f32x4 (&r)[F4], 
     for (int i = 0; i < F4; ++i) {
         const int idx = tid + i * 256;
         if (LAY == KMAJOR) {
-            const int row = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
-            *reinterpret_cast<f32x4*>(s + row * STRIDE + kq) = r[i];
+            const int row = idx / (BK / 4), q = idx % (BK / 4);
+            *reinterpret_cast<f32x4*>(s + PanelGeom<LAY, ROWS, BK>::kchunk(row, q)) = r[i];
         } else {
             const int kr = idx / (ROWS / 4), rq = (idx % (ROWS / 4)) * 4;
             *reinterpret_cast<f32x4*>(s + kr * STRIDE + rq) = r[i];
@@ -135,7 +145,7 @@ template <int LAY, int ROWS, int BK>
 __device__ __forceinline__ f32x4 panel_frag(const float* s, int row, int c, int h) {
     constexpr int STRIDE = PanelGeom<LAY, ROWS, BK>::STRIDE;
     if (LAY == KMAJOR) {
-        return *reinterpret_cast<const f32x4*>(s + row * STRIDE + c * 8 + 4 * h);
+        return *reinterpret_cast<const f32x4*>(s + PanelGeom<LAY, ROWS, BK>::kchunk(row, 2 * c + h));
     } else {
         f32x4 v;
         const float* q = s + (c * 8 + 4 * h) * STRIDE + row;
