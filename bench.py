@@ -47,6 +47,26 @@ def synth(n_rows, rank_seed, device):
     return Y, D0
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    summary (profiles/*_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc
+    passes, gfx950 FETCH_SIZE x2 correction).  PMC counters cannot be read inside this
+    process, so the number is the one measured by tools/profile_round.sh on this same
+    command at N = 1; None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))
+    if not files:
+        return None, 'no committed PMC summary'
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d.items():
+            if kernel_key in k and 'hbm_bytes_corrected' in v:
+                return v['hbm_bytes_corrected'], 'from %s (N=1 run)' % os.path.basename(files[-1])
+    except Exception as e:  # pragma: no cover
+        return None, 'unreadable PMC summary: %s' % e
+    return None, 'kernel not in PMC summary'
+
+
 def cpu_baseline(budget_s=20.0):
     """The oracle (NumPy restatement of the reference's 6-GEMM formulation) on a bounded
     row sample of the same workload, scaled to whole-job iterations/s."""
@@ -179,12 +199,15 @@ def main():
         }
         # dominant kernel: the fused Y.D^T GEMM + MU quotient (2.N.K.F flop per launch)
         dom = prof.get('x_update')
+        traffic, traffic_src = pmc_traffic('0, 0, false, EpiMuNum<float>')
         if dom:
             flops = 2.0 * rows * N_ATOMS * N_FEAT
             ach = flops / (dom['ms_avg'] * 1e-3) / 1e12
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel<NT, EpiMuNum> (Y.D^T + quotient)',
                                'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                               'traffic_note': traffic_src,
+                               'algorithmic_bytes': 4.0 * (rows * N_FEAT + N_ATOMS * N_FEAT + 3 * rows * N_ATOMS),
                                'launch_ms': dom['ms_avg'], 'launches': dom['launches']}
         st = prof.get('stats')
         if st:
