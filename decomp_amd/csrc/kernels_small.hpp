@@ -131,7 +131,8 @@ __global__ void __launch_bounds__(256) row_normalize_kernel(const T* __restrict_
                                                             long F, int strict,
                                                             const T* __restrict__ ref, long ld_ref,
                                                             T* __restrict__ out, long ld_out,
-                                                            real_t<T>* __restrict__ rowmax) {
+                                                            real_t<T>* __restrict__ rowmax,
+                                                            real_t<T>* __restrict__ norm_out = nullptr) {
     typedef real_t<T> R;
     __shared__ R sh[4];
     __shared__ R s_inv;
@@ -143,6 +144,7 @@ __global__ void __launch_bounds__(256) row_normalize_kernel(const T* __restrict_
     if (threadIdx.x == 0) {
         if (!strict) tot = tot > R(1) ? tot : R(1);
         s_inv = sqrt(tot);
+        if (norm_out != nullptr) norm_out[row] = s_inv;
     }
     __syncthreads();
     const R nrm = s_inv;

@@ -1,0 +1,633 @@
+// Batched LASSO / NNLS inner solves on the device (float, double, complex64, complex128).
+//
+// Reference path restated as kernels:
+//   decomp/lasso.py:97-189    solve_fastpath: row-normalise A, rescale alpha / tol / x
+//   decomp/lasso.py:192-241   soft thresholds (real, complex, positive)
+//   decomp/lasso.py:244-271   one proximal-gradient step, plain and masked
+//   decomp/lasso.py:274-445   ista / acc_ista / fista (+ 2-D mask variants)
+//   decomp/lasso.py:526-583   coordinate descent (+ mask variant)
+//   decomp/math_utils/eigen.py:9-20  Gershgorin bound
+//
+// Structure on the GPU: the per-iteration x.AAt product is the GEMM; everything the
+// reference does elementwise around it (gradient, step, soft threshold, momentum
+// extrapolation, |dx| - tol stop test) is the GEMM's epilogue, so one iteration is ONE
+// kernel (two when a 2-D mask forces the chained (x A o M) A^H form).  The step size
+// 1/L stays on the device; the host only reads a 4-byte flag on every 10th iteration,
+// exactly where the reference evaluates its stop test.
+// Coordinate descent uses the Gram form (rows of A are unit norm, lasso.py:528):
+//   g = y A^H - x AAt;  x_k <- S(g_k + x_k AAt_kk, alpha_k);  g -= dx_k AAt[k, :]
+// which is what lasso.py:539-548 computes, at 2NK^2 instead of 2NKF.K flops per sweep.
+#pragma once
+#include <math.h>
+
+#include "gemm.hpp"
+#include "handle.hpp"
+#include "kernels_small.hpp"
+#include "nmf_impl.hpp"  // DCP_LAUNCH_OK, column_sums
+
+namespace dcp {
+
+enum { PROX_REAL = 0, PROX_COMPLEX = 1, PROX_POSITIVE = 2 };
+
+// ---- proximal operators ------------------------------------------------------------------
+template <int PROX, class T>
+__device__ __forceinline__ T prox_apply(T z, real_t<T> thr) {
+    typedef real_t<T> R;
+    if constexpr (scalar_traits<T>::is_complex) {
+        // lasso.py:223-225: max(|z| - t, 0) * z / (|z| + 1e-15)
+        const R r = absval(z);
+        const R m = (r - thr) > R(0) ? (r - thr) : R(0);
+        const R den = r + R(1.0e-15);
+        T sgn;
+        sgn.re = z.re / den;
+        sgn.im = z.im / den;
+        return scale(sgn, m);
+    } else {
+        if (PROX == PROX_POSITIVE) {  // lasso.py:241
+            const T v = z - thr;
+            return v > T(0) ? v : T(0);
+        }
+        // lasso.py:206-207: max(|z| - t, 0) * sign(z)
+        const T m = (absval(z) - thr) > T(0) ? (absval(z) - thr) : T(0);
+        const T sg = z > T(0) ? T(1) : (z < T(0) ? T(-1) : (z == T(0) ? T(0) : z /*NaN*/));
+        return m * sg;
+    }
+}
+
+// ---- epilogues -------------------------------------------------------------------------------
+// One proximal-gradient step fused into the GEMM that yields back = v.AAt (or (vA o M)A^H):
+//   z = v + Linv * (yAt - back) ; x_new = S(z, Linv*alpha_k [* rowscale_n]) ;
+//   v_next = x_new + coef * (x_new - x_prev) ; violation flag |x_new - x_prev| - tol_k >= 0
+template <class T, int PROX>
+struct EpiProxStep {
+    typedef real_t<T> R;
+    const T* yAt;
+    const T* v;
+    const T* xprev;
+    T* xnew;
+    T* vnext;  // nullable (plain ista)
+    long ld;
+    const R* Linv;      // device scalar
+    const R* alpha;     // [K]
+    const R* tolk;      // [K]
+    const R* rowscale;  // nullable [N]  (2-D mask: sum_f mask[n, f])
+    R coef;
+    int check;
+    int* flag;
+    __device__ __forceinline__ void operator()(int r, int c, T back, int) const {
+        const long i = (long)r * ld + c;
+        const R li = Linv[0];
+        const T z = add(v[i], scale(sub(yAt[i], back), li));
+        R thr = li * alpha[c];
+        if (rowscale != nullptr) thr = li * (alpha[c] * rowscale[r]);
+        const T xn = prox_apply<PROX>(z, thr);
+        xnew[i] = xn;
+        const T d = sub(xn, xprev[i]);
+        if (vnext != nullptr) vnext[i] = add(xn, scale(d, coef));
+        if (check && !((absval(d) - tolk[c]) < R(0))) *flag = 1;
+    }
+};
+
+// out = base - acc   (g = yAt - x.AAt for coordinate descent)
+template <class T>
+struct EpiSubFrom {
+    const T* base;
+    long ld_base;
+    T* out;
+    long ld_out;
+    __device__ __forceinline__ void operator()(int r, int c, T v, int) const {
+        out[(long)r * ld_out + c] = sub(base[(long)r * ld_base + c], v);
+    }
+};
+
+// out = base - acc * mask   (r = y o M - (x A) o M for masked coordinate descent)
+template <class T>
+struct EpiMaskedResidual {
+    const T* base;
+    const real_t<T>* mask;
+    T* out;
+    long ld;
+    __device__ __forceinline__ void operator()(int r, int c, T v, int) const {
+        const long i = (long)r * ld + c;
+        out[i] = sub(base[i], scale(v, mask[i]));
+    }
+};
+
+// ---- small kernels -----------------------------------------------------------------------------
+// alpha_k = (alpha / s_k) * nvalid ;  tol_k = tol * s_k        (lasso.py:129-130,135-138)
+template <class R>
+__global__ void __launch_bounds__(256) lasso_scalars_kernel(const R* __restrict__ s, long K, R alpha,
+                                                            R tol, const R* __restrict__ nvalid_dev,
+                                                            R nvalid_const, R* __restrict__ alphak,
+                                                            R* __restrict__ tolk) {
+    const R nv = nvalid_dev != nullptr ? nvalid_dev[0] : nvalid_const;
+    for (long k = blockIdx.x * 256L + threadIdx.x; k < K; k += (long)gridDim.x * 256L) {
+        alphak[k] = (alpha / s[k]) * nv;
+        tolk[k] = tol * s[k];
+    }
+}
+
+// out[n, k] = x[n, k] * s[k]  (mul != 0)  or  x[n, k] / s[k]     (lasso.py:131,189)
+template <class T>
+__global__ void __launch_bounds__(256) col_scale_kernel(const T* __restrict__ x, const real_t<T>* __restrict__ s,
+                                                        long rows, long K, int mul, T* __restrict__ out) {
+    typedef real_t<T> R;
+    const long n = rows * K;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const long k = i % K;
+        const R sk = s[k];
+        T v = x[i];
+        if (mul) {
+            v = scale(v, sk);
+        } else {
+            if constexpr (scalar_traits<T>::is_complex) { v.re = v.re / sk; v.im = v.im / sk; }
+            else v = v / sk;
+        }
+        out[i] = v;
+    }
+}
+
+// Linv = 1 / max_j sum_i |AAt[i, j]|   (eigen.py:20, lasso.py:286).  One workgroup.
+template <class T>
+__global__ void __launch_bounds__(256) gershgorin_inv_kernel(const T* __restrict__ AAt, long K,
+                                                             real_t<T>* __restrict__ Linv) {
+    typedef real_t<T> R;
+    __shared__ R sh[4];
+    R best = 0;
+    for (long j = threadIdx.x; j < K; j += 256) {
+        R acc = 0;
+        for (long i = 0; i < K; ++i) acc += absval(AAt[i * K + j]);
+        best = (acc > best || acc != acc) ? acc : best;
+    }
+    R m = block_max_256(best, sh);
+    if (threadIdx.x == 0) Linv[0] = R(1) / m;
+}
+
+// out[f] = v[f] / count   (mean over the batch of the mask, lasso.py:300-303)
+template <class R>
+__global__ void __launch_bounds__(256) scale_vec_kernel(const R* __restrict__ v, long n, R divisor,
+                                                        R* __restrict__ out) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
+        out[i] = v[i] / divisor;
+}
+
+// sum of a real vector -> out[0]   (one workgroup; sum(mask) for 1-D masks)
+template <class R>
+__global__ void __launch_bounds__(256) vec_sum_kernel(const R* __restrict__ v, long n, R* __restrict__ out) {
+    __shared__ R sh[4];
+    R acc = 0;
+    for (long i = threadIdx.x; i < n; i += 256) acc += v[i];
+    R t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+// Coordinate-descent sweeps in Gram form.  One wave per row; lane l holds columns l + 64m.
+// Sweeps [sweep0, sweep0 + nsweeps); the LAST one is a check sweep when check_last != 0.
+template <class T, int PROX, int MAXM>
+__global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __restrict__ G,
+                                                      const T* __restrict__ AAt,
+                                                      const real_t<T>* __restrict__ alphak,
+                                                      const real_t<T>* __restrict__ tolk, long rows,
+                                                      int K, int nsweeps, int check_last,
+                                                      int* __restrict__ flag) {
+    typedef real_t<T> R;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int M = (K + 63) / 64;
+    T x[MAXM], g[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+        const int c = lane + 64 * m;
+        x[m] = (m < M && c < K) ? X[row * K + c] : zero_of<T>();
+        g[m] = (m < M && c < K) ? G[row * K + c] : zero_of<T>();
+    }
+    bool viol = false;
+    for (int s = 0; s < nsweeps; ++s) {
+        const bool check = check_last && (s == nsweeps - 1);
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) {
+            if (m >= M) break;
+            const int kend = min(64, K - 64 * m);
+            for (int kk = 0; kk < kend; ++kk) {
+                const int k = 64 * m + kk;
+                T gk, xk;
+                if constexpr (scalar_traits<T>::is_complex) {
+                    gk.re = __shfl(g[m].re, kk, 64); gk.im = __shfl(g[m].im, kk, 64);
+                    xk.re = __shfl(x[m].re, kk, 64); xk.im = __shfl(x[m].im, kk, 64);
+                } else {
+                    gk = __shfl(g[m], kk, 64);
+                    xk = __shfl(x[m], kk, 64);
+                }
+                const T akk = AAt[(long)k * K + k];
+                const T z = add(gk, mul(xk, akk));
+                const T xn = prox_apply<PROX>(z, alphak[k]);
+                const T d = sub(xn, xk);
+                if (check && !((absval(d) - tolk[k]) < R(0))) viol = true;
+                if (lane == kk) x[m] = xn;
+                if (abs2(d) != R(0)) {   // wave-uniform: a zero step leaves g unchanged
+                    const T* arow = AAt + (long)k * K;
+#pragma unroll
+                    for (int mm = 0; mm < MAXM; ++mm) {
+                        const int c = lane + 64 * mm;
+                        if (mm < M && c < K) g[mm] = sub(g[mm], mul(d, arow[c]));
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+        const int c = lane + 64 * m;
+        if (m < M && c < K) {
+            X[row * K + c] = x[m];
+            G[row * K + c] = g[m];
+        }
+    }
+    if (viol && lane == 0) *flag = 1;
+}
+
+// Masked coordinate descent, as written in lasso.py:555-583: with r = (y - x.A) o M kept in
+// memory,  x_k <- S(r . conj(A_k) + x_k (A_k . conj(A_k)), alpha_nk);  r -= dx (A_k o M).
+// One workgroup per row; F-length dot products by block reduction.  (Parity path for
+// lasso.solve(mask=...); not on a BASELINE config.)
+template <class T, int PROX>
+__global__ void __launch_bounds__(256) cd_mask_kernel(T* __restrict__ X, T* __restrict__ Rres,
+                                                      const T* __restrict__ A,
+                                                      const real_t<T>* __restrict__ mask,
+                                                      const real_t<T>* __restrict__ akk,
+                                                      const real_t<T>* __restrict__ alphak,
+                                                      const real_t<T>* __restrict__ rowscale,
+                                                      const real_t<T>* __restrict__ tolk, int K, long F,
+                                                      int nsweeps, int check_last,
+                                                      int* __restrict__ flag) {
+    typedef real_t<T> R;
+    __shared__ R sh_re[4], sh_im[4];
+    __shared__ T s_d;
+    const long row = blockIdx.x;
+    T* r = Rres + row * F;
+    const R* mrow = mask + row * F;
+    bool viol = false;
+    for (int s = 0; s < nsweeps; ++s) {
+        const bool check = check_last && (s == nsweeps - 1);
+        for (int k = 0; k < K; ++k) {
+            const T* ak = A + (long)k * F;
+            R pre = 0, pim = 0;
+            for (long f = threadIdx.x; f < F; f += 256) {
+                const T t = mul(r[f], conj_of(ak[f]));
+                pre += real_part(t);
+                if constexpr (scalar_traits<T>::is_complex) pim += t.im;
+            }
+            const R tre = block_sum_256(pre, sh_re);
+            R tim = 0;
+            if constexpr (scalar_traits<T>::is_complex) tim = block_sum_256(pim, sh_im);
+            if (threadIdx.x == 0) {
+                T dot;
+                if constexpr (scalar_traits<T>::is_complex) { dot.re = tre; dot.im = tim; }
+                else dot = tre;
+                const T xk = X[row * K + k];
+                const T z = add(dot, scale(xk, akk[k]));
+                const T xn = prox_apply<PROX>(z, alphak[k] * rowscale[row]);
+                const T d = sub(xn, xk);
+                if (check && !((absval(d) - tolk[k]) < R(0))) *flag = 1;
+                X[row * K + k] = xn;
+                s_d = d;
+            }
+            __syncthreads();
+            const T d = s_d;
+            if (abs2(d) != R(0))
+                for (long f = threadIdx.x; f < F; f += 256)
+                    r[f] = sub(r[f], mul(d, scale(ak[f], mrow[f])));
+            __syncthreads();
+        }
+    }
+    (void)viol;
+}
+
+// akk[k] = sum_f |A[k, f]|^2  is what A_k . conj(A_k) evaluates to; computed by the row-norm
+// kernel as s^2.  This helper squares a vector.
+template <class R>
+__global__ void __launch_bounds__(256) square_vec_kernel(const R* __restrict__ v, long n, R* __restrict__ out) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
+        out[i] = v[i] * v[i];
+}
+
+// ---- the solver ----------------------------------------------------------------------------------
+template <class T>
+struct LassoWs {
+    typedef real_t<T> R;
+    T* An = nullptr;     // [K,F] row-normalised (and 1-D-masked) design matrix
+    T* Ym = nullptr;     // [N,F] y o mask (any mask)
+    T* yAt = nullptr;    // [N,K]
+    T* AAt = nullptr;    // [K,K]
+    T* Am = nullptr;     // [K,F] A o mean(mask)  (2-D mask: Lipschitz bound only)
+    T* slabs = nullptr;  // split-K partials of AAt
+    T* xb[4] = {nullptr, nullptr, nullptr, nullptr};  // iterates [N,K]
+    T* G = nullptr;      // [N,K] CD gradient
+    T* T1 = nullptr;     // [N,F] (v A) o M
+    R* s = nullptr;      // [K] row norms of A
+    R* alphak = nullptr; // [K]
+    R* tolk = nullptr;   // [K]
+    R* akk = nullptr;    // [K]
+    R* rowscale = nullptr;  // [N]
+    R* mbar = nullptr;   // [F]
+    R* part = nullptr;   // column-sum partials [64, F]
+    R* scal = nullptr;   // [4]: Linv, nvalid
+    int* flag = nullptr;
+    size_t slab_count = 0;
+};
+
+template <class T>
+inline void lasso_plan(WsPlan& p, int64_t N, int64_t F, int64_t K, int mask_ndim, int method) {
+    typedef real_t<T> R;
+    p.add<T>((size_t)K * F);
+    if (mask_ndim != 0) p.add<T>((size_t)N * F);
+    p.add<T>((size_t)N * K);
+    p.add<T>((size_t)K * K);
+    if (mask_ndim == 2) p.add<T>((size_t)K * F);
+    p.add<T>((size_t)kMaxSplits * K * K);
+    for (int i = 0; i < 4; ++i) p.add<T>((size_t)N * K);
+    if (method == DCP_LASSO_CD && mask_ndim != 2) p.add<T>((size_t)N * K);
+    if (mask_ndim == 2) p.add<T>((size_t)N * F);
+    for (int i = 0; i < 4; ++i) p.add<R>((size_t)K);
+    p.add<R>((size_t)N);
+    p.add<R>((size_t)F);
+    p.add<R>((size_t)64 * F);
+    p.add<R>(4);
+    p.add<int>(4);
+}
+
+template <class T>
+inline int lasso_carve(dcp_handle* h, LassoWs<T>& w, int64_t N, int64_t F, int64_t K, int mask_ndim,
+                       int method) {
+    typedef real_t<T> R;
+    w.An = ws_alloc<T>(h, (size_t)K * F);
+    if (mask_ndim != 0) w.Ym = ws_alloc<T>(h, (size_t)N * F);
+    w.yAt = ws_alloc<T>(h, (size_t)N * K);
+    w.AAt = ws_alloc<T>(h, (size_t)K * K);
+    if (mask_ndim == 2) w.Am = ws_alloc<T>(h, (size_t)K * F);
+    w.slab_count = (size_t)kMaxSplits * K * K;
+    w.slabs = ws_alloc<T>(h, w.slab_count);
+    for (int i = 0; i < 4; ++i) w.xb[i] = ws_alloc<T>(h, (size_t)N * K);
+    if (method == DCP_LASSO_CD && mask_ndim != 2) w.G = ws_alloc<T>(h, (size_t)N * K);
+    if (mask_ndim == 2) w.T1 = ws_alloc<T>(h, (size_t)N * F);
+    w.s = ws_alloc<R>(h, (size_t)K);
+    w.alphak = ws_alloc<R>(h, (size_t)K);
+    w.tolk = ws_alloc<R>(h, (size_t)K);
+    w.akk = ws_alloc<R>(h, (size_t)K);
+    w.rowscale = ws_alloc<R>(h, (size_t)N);
+    w.mbar = ws_alloc<R>(h, (size_t)F);
+    w.part = ws_alloc<R>(h, (size_t)64 * F);
+    w.scal = ws_alloc<R>(h, 4);
+    w.flag = ws_alloc<int>(h, 4);
+    if (!w.An || !w.yAt || !w.AAt || !w.slabs || !w.xb[3] || !w.s || !w.alphak || !w.tolk ||
+        !w.akk || !w.rowscale || !w.mbar || !w.part || !w.scal || !w.flag ||
+        (mask_ndim != 0 && !w.Ym) || (mask_ndim == 2 && (!w.Am || !w.T1)) ||
+        (method == DCP_LASSO_CD && mask_ndim != 2 && !w.G))
+        return fail(h, DCP_ERR_INTERNAL, "lasso workspace plan mismatch");
+    return DCP_OK;
+}
+
+// C[K,K] = P . Q^H for [K,F] operands, reduction over F split into ordered slabs.
+template <class T>
+inline int gram_kk(dcp_handle* h, const T* P, const T* Q, int K, int F, LassoWs<T>& w, T* out) {
+    GemmArgs<T> g;
+    g.A = P; g.lda = F; g.B = Q; g.ldb = F; g.M = K; g.N = K; g.K = F;
+    g.conjB = true;
+    plan_splits<FORM_NT>(g, kSplitTarget / 4, kMaxSplits);
+    if ((size_t)g.ksplits * K * K > w.slab_count) return fail(h, DCP_ERR_INTERNAL, "lasso slab plan");
+    DCP_LAUNCH_OK(h, (gemm<FORM_NT>(h->stream, g, EpiSlab<T>{w.slabs, K, (long)K * K})));
+    hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * K)), dim3(256), 0, h->stream,
+                       w.slabs, (long)K * K, g.ksplits, (long)K * K, out);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    return DCP_OK;
+}
+
+template <class T>
+inline int read_flag(dcp_handle* h, int* flag_dev, int* host_flag, bool* violated) {
+    DCP_HIP_OK(h, hipMemcpyAsync(host_flag, flag_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    *violated = (*host_flag != 0);
+    return DCP_OK;
+}
+
+// solve_fastpath (lasso.py:97-189).  Y [N,F], A [K,F], X [N,K] (in: initial estimate, out:
+// solution), mask: null, [F] (mask_ndim 1) or [N,F] (mask_ndim 2).  *it_out as the reference.
+template <class T, int PROX>
+inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mask_ndim, const T* A,
+                       T* X, int64_t N64, int64_t F64, int64_t K64, real_t<T> alpha, real_t<T> tol,
+                       int maxiter, int method, int* it_out, LassoWs<T>& w) {
+    typedef real_t<T> R;
+    hipStream_t st = h->stream;
+    const int N = (int)N64, F = (int)F64, K = (int)K64;
+    void* hostv = nullptr;
+    DCP_TRY(host_scratch(h, 64, &hostv));
+    int* host_flag = reinterpret_cast<int*>(hostv);
+
+    // ---- 1-D mask folds into y and A (lasso.py:120-122); any mask: Ym = y o M ----
+    const T* Ause = A;
+    const T* Yuse = Y;
+    if (mask_ndim == 1) {
+        hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for((long)K * F)), dim3(256), 0, st, A, mask,
+                           (long)K, (long)F, 0L, w.An);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        Ause = w.An;
+        hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for((long)N * F)), dim3(256), 0, st, Y, mask,
+                           (long)N, (long)F, 0L, w.Ym);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        Yuse = w.Ym;
+        hipLaunchKernelGGL((vec_sum_kernel<R>), dim3(1), dim3(256), 0, st, mask, (long)F, w.scal + 1);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+    } else if (mask_ndim == 2) {
+        hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for((long)N * F)), dim3(256), 0, st, Y, mask,
+                           (long)N, (long)F, (long)F, w.Ym);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        Yuse = w.Ym;
+        hipLaunchKernelGGL((rowsum_kernel<R>), dim3(N), dim3(256), 0, st, mask, (long)F, (long)F,
+                           w.rowscale);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+    }
+    // ---- A scaling (lasso.py:124-131): s = |A_k|, An = A / s, alpha/s, tol*s, x*s ----
+    hipLaunchKernelGGL((row_normalize_kernel<T>), dim3(K), dim3(256), 0, st, Ause, (long)F, (long)F, 1,
+                       (const T*)nullptr, 0L, w.An, (long)F, (R*)nullptr, w.s);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    hipLaunchKernelGGL((lasso_scalars_kernel<R>), dim3(grid_for(K, 64)), dim3(256), 0, st, w.s, (long)K,
+                       alpha, tol, mask_ndim == 1 ? w.scal + 1 : (const R*)nullptr,
+                       mask_ndim == 2 ? R(1) : R(F), w.alphak, w.tolk);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    T* xcur = w.xb[0];
+    hipLaunchKernelGGL((col_scale_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st, (const T*)X,
+                       (const R*)w.s, (long)N, (long)K, 1, xcur);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+
+    // ---- yAt = (y o M) An^H ----
+    {
+        GemmArgs<T> a;
+        a.A = Yuse; a.lda = F; a.B = w.An; a.ldb = F; a.M = N; a.N = K; a.K = F; a.conjB = true;
+        DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a, EpiStore<T>{w.yAt, K})));
+    }
+    const R* rowscale = mask_ndim == 2 ? w.rowscale : nullptr;
+    int it = maxiter - 1;
+    T* result = xcur;
+
+    if (method == DCP_LASSO_CD && mask_ndim != 2) {
+        // ---------------- coordinate descent, Gram form ----------------
+        DCP_TRY(gram_kk<T>(h, w.An, w.An, K, F, w, w.AAt));
+        {   // g = yAt - x AAt
+            GemmArgs<T> a;
+            a.A = xcur; a.lda = K; a.B = w.AAt; a.ldb = K; a.M = N; a.N = K; a.K = K;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiSubFrom<T>{w.yAt, K, w.G, K})));
+        }
+        if (K > 64 * 16) return fail(h, DCP_ERR_UNSUPPORTED, "cd: n_features > 1024 not supported");
+        int sweep = 0;
+        while (sweep < maxiter) {
+            // run up to and including the next check sweep (sweeps 0, 10, 20, ...)
+            int last = (sweep % 10 == 0) ? sweep : (sweep / 10 + 1) * 10;
+            int check_last = 1;
+            if (last > maxiter - 1) { last = maxiter - 1; check_last = (last % 10 == 0); }
+            const int ns = last - sweep + 1;
+            DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
+            const int grid = (N + 3) / 4;
+#define DCP_CD_LAUNCH(MM)                                                                            \
+    hipLaunchKernelGGL((cd_gram_kernel<T, PROX, MM>), dim3(grid), dim3(256), 0, st, xcur, w.G,       \
+                       (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,        \
+                       check_last, w.flag)
+            if (K <= 64) DCP_CD_LAUNCH(1);
+            else if (K <= 128) DCP_CD_LAUNCH(2);
+            else if (K <= 256) DCP_CD_LAUNCH(4);
+            else if (K <= 512) DCP_CD_LAUNCH(8);
+            else DCP_CD_LAUNCH(16);
+#undef DCP_CD_LAUNCH
+            DCP_LAUNCH_OK(h, hipGetLastError());
+            sweep = last + 1;
+            if (check_last) {
+                bool viol = true;
+                DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
+                if (!viol) { it = last; break; }
+            }
+        }
+        result = xcur;
+    } else if (method == DCP_LASSO_CD) {
+        // ---------------- coordinate descent with a 2-D mask (as written) ----------------
+        {   // r = y o M - (x An) o M
+            GemmArgs<T> a;
+            a.A = xcur; a.lda = K; a.B = w.An; a.ldb = F; a.M = N; a.N = F; a.K = K;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiMaskedResidual<T>{w.Ym, mask, w.T1, (long)F})));
+        }
+        // A_k . conj(A_k) of the normalised rows, as the reference evaluates it (== 1 up to rounding)
+        hipLaunchKernelGGL((row_normalize_kernel<T>), dim3(K), dim3(256), 0, st, (const T*)w.An, (long)F,
+                           (long)F, 1, (const T*)nullptr, 0L, w.Am, (long)F, (R*)nullptr, w.akk);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        hipLaunchKernelGGL((square_vec_kernel<R>), dim3(grid_for(K, 64)), dim3(256), 0, st,
+                           (const R*)w.akk, (long)K, w.akk);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        int sweep = 0;
+        while (sweep < maxiter) {
+            int last = (sweep % 10 == 0) ? sweep : (sweep / 10 + 1) * 10;
+            int check_last = 1;
+            if (last > maxiter - 1) { last = maxiter - 1; check_last = (last % 10 == 0); }
+            const int ns = last - sweep + 1;
+            DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
+            hipLaunchKernelGGL((cd_mask_kernel<T, PROX>), dim3(N), dim3(256), 0, st, xcur, w.T1,
+                               (const T*)w.An, mask, (const R*)w.akk, (const R*)w.alphak,
+                               (const R*)w.rowscale, (const R*)w.tolk, K, (long)F, ns, check_last,
+                               w.flag);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+            sweep = last + 1;
+            if (check_last) {
+                bool viol = true;
+                DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
+                if (!viol) { it = last; break; }
+            }
+        }
+        result = xcur;
+    } else {
+        // ---------------- ista / acc_ista / fista ----------------
+        if (mask_ndim == 2) {
+            // Lipschitz bound from (A o mean_batch(M)) A^H   (lasso.py:317)
+            DCP_TRY(column_sums<R>(h, mask, F, N, F, w.part, w.mbar));
+            hipLaunchKernelGGL((scale_vec_kernel<R>), dim3(grid_for(F, 64)), dim3(256), 0, st,
+                               (const R*)w.mbar, (long)F, R(N), w.mbar);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+            hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for((long)K * F)), dim3(256), 0, st,
+                               (const T*)w.An, (const R*)w.mbar, (long)K, (long)F, 0L, w.Am);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+            DCP_TRY(gram_kk<T>(h, w.Am, w.An, K, F, w, w.AAt));
+        } else {
+            DCP_TRY(gram_kk<T>(h, w.An, w.An, K, F, w, w.AAt));
+        }
+        hipLaunchKernelGGL((gershgorin_inv_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)w.AAt,
+                           (long)K, w.scal);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+
+        // Buffer roles (pointers rotate over the four [N,K] buffers):
+        //   P = the iterate the stop test compares with (the reference's x0)
+        //   V = the point fed to the step (x0 for ista, v / w0 with momentum)
+        //   Nw, Vn = this iteration's outputs (x0_new and the next V)
+        const bool mom = (method != DCP_LASSO_ISTA);
+        T* P = xcur;
+        T* V = xcur;
+        T* lastP = xcur;
+        T* lastNw = xcur;
+        double beta = 1.0;
+        bool converged = false;
+        for (int i = 0; i < maxiter; ++i) {
+            T* Nw = nullptr;
+            T* Vn = nullptr;
+            for (int b = 0; b < 4; ++b) {
+                T* c = w.xb[b];
+                if (c == P || c == V) continue;
+                if (Nw == nullptr) Nw = c;
+                else if (Vn == nullptr) Vn = c;
+            }
+            R coef = R(0);
+            double beta_new = beta;
+            if (method == DCP_LASSO_ACC_ISTA) {
+                coef = (R)((double)i / (double)(i + 3));                    // lasso.py:353
+            } else if (method == DCP_LASSO_FISTA) {
+                beta_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * beta * beta));     // lasso.py:411
+                coef = (R)((beta - 1.0) / beta_new);
+            }
+            const int check = (i % 10 == 0) ? 1 : 0;
+            if (check) DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
+            EpiProxStep<T, PROX> epi{w.yAt, V, P, Nw, mom ? Vn : (T*)nullptr, (long)K, w.scal,
+                                     w.alphak, w.tolk, rowscale, coef, check, w.flag};
+            if (mask_ndim == 2) {
+                GemmArgs<T> a1;   // T1 = (V An) o M
+                a1.A = V; a1.lda = K; a1.B = w.An; a1.ldb = F; a1.M = N; a1.N = F; a1.K = K;
+                DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a1, EpiMulMask<T>{mask, F, w.T1, F})));
+                GemmArgs<T> a2;   // back = T1 An^H, prox step in the epilogue
+                a2.A = w.T1; a2.lda = F; a2.B = w.An; a2.ldb = F; a2.M = N; a2.N = K; a2.K = F;
+                a2.conjB = true;
+                DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a2, epi)));
+            } else {
+                GemmArgs<T> a;    // back = V AAt, prox step in the epilogue
+                a.A = V; a.lda = K; a.B = w.AAt; a.ldb = K; a.M = N; a.N = K; a.K = K;
+                DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, epi)));
+            }
+            if (check) {
+                bool viol = true;
+                DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
+                if (!viol) { it = i; result = Nw; converged = true; break; }   // lasso.py:293-294
+            }
+            lastP = P;
+            lastNw = Nw;
+            P = Nw;
+            V = mom ? Vn : Nw;
+            beta = beta_new;
+        }
+        // QUIRK: on exhaustion ista / fista return the latest iterate, acc_ista the one
+        // before it (its `x0 = x0_new` sits at the top of the loop body, lasso.py:351-357).
+        if (!converged) result = (method == DCP_LASSO_ACC_ISTA) ? lastP : lastNw;
+    }
+
+    // ---- x / s  (lasso.py:189) ----
+    hipLaunchKernelGGL((col_scale_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st,
+                       (const T*)result, (const R*)w.s, (long)N, (long)K, 0, X);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    DCP_HIP_OK(h, hipStreamSynchronize(st));
+    *it_out = it;
+    return DCP_OK;
+}
+
+}  // namespace dcp

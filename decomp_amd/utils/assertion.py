@@ -72,3 +72,16 @@ def assert_nonnegative(x):
         return
     assert _arrays.np_dtype(x).kind != 'c'
     assert _arrays.count_negative(x) == 0
+
+
+def assert_nonnegative_host_or_device(x):
+    """assert_nonnegative for an array that has not been sent to the GPU yet (the LASSO
+    mask, lasso.py:78): NumPy arrays are scanned where they are, torch CUDA tensors by the
+    HIP scan kernel.  Host-side argument validation, not part of the compute path."""
+    if x is None:
+        return
+    if _arrays.is_torch(x):
+        assert_nonnegative(x.contiguous())
+        return
+    assert x.dtype.kind != 'c'
+    assert bool((x >= 0.0).all())

@@ -143,6 +143,30 @@ int dcp_nmf_residual_f32(dcp_handle* h, const float* Y, const float* mask, const
 int dcp_nmf_residual_f64(dcp_handle* h, const double* Y, const double* mask, const double* X,
                          const double* D, int64_t N, int64_t F, int64_t K, double* out);
 
+/* ---- batched LASSO / NNLS ---------------------------------------------------------- */
+/* decomp/lasso.py:97-189 (solve_fastpath, everything after validation):
+ *   argmin_x 1/(2n) |y - x A|^2 + alpha |x|_1  for every row of Y[N,F] (batch dims
+ *   flattened by the caller), A[K,F], X[N,K] in: initial estimate, out: solution.
+ * mask: NULL (mask_ndim 0), [F] (mask_ndim 1, lasso.py:120-122) or [N,F] (mask_ndim 2,
+ * lasso.py:160-186), real dtype of the problem.  method: DCP_LASSO_*; positive != 0 selects
+ * the `_pos` (NNLS) proximal operator (real dtypes only, lasso.py:92).
+ * *it_out (host) is the reference's iteration count: the index of the first iteration
+ * i % 10 == 0 at which max(|dx| - tol) < 0, else maxiter - 1 (with the reference's
+ * choice of returned iterate per method, lasso.py:297,357,415).  The coordinate-descent
+ * solver supports K <= 1024.  Synchronises the stream before returning. */
+int dcp_lasso_f32(dcp_handle* h, const float* Y, const float* mask, int mask_ndim, const float* A,
+                  float* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                  int method, int positive, int* it_out);
+int dcp_lasso_f64(dcp_handle* h, const double* Y, const double* mask, int mask_ndim, const double* A,
+                  double* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                  int method, int positive, int* it_out);
+int dcp_lasso_c64(dcp_handle* h, const void* Y, const float* mask, int mask_ndim, const void* A,
+                  void* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                  int method, int positive, int* it_out);
+int dcp_lasso_c128(dcp_handle* h, const void* Y, const double* mask, int mask_ndim, const void* A,
+                   void* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                   int method, int positive, int* it_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,130 @@
+"""GPU parity: decomp_amd.lasso (HIP, through the C ABI) against the golden vectors of the
+real reference (every starred method x {real, complex, float32} x {no mask, 1-D, 2-D mask}
+x {vector, matrix, tensor}) and against the CPU oracle at larger sizes."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _g():
+    return np.load(os.path.join(GOLDEN, 'lasso_golden.npz'), allow_pickle=False)
+
+
+def _err(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) / max(1.0, float(np.max(np.abs(b))))
+
+
+@pytest.mark.parametrize('kind', ['f64', 'c128', 'f32'])
+@pytest.mark.parametrize('sname', ['vec', 'mat', 'ten'])
+@pytest.mark.parametrize('mname', ['nomask', 'mask1d', 'mask2d'])
+def test_golden_cases(kind, sname, mname):
+    from decomp_amd import lasso
+    g = _g()
+    base = 'lasso_%s_%s' % (kind, sname)
+    y, A = g[base + '/y'], g[base + '/A']
+    mask = None if mname == 'nomask' else g[base + '/' + mname]
+    methods = ['ista', 'acc_ista', 'fista', 'cd']
+    if kind != 'c128':
+        methods += [m + '_pos' for m in methods]
+    for method in methods:
+        for tag in ('conv', 'exh'):
+            name = '%s/%s/%s/%s' % (base, mname, method, tag)
+            it, x = lasso.solve(y.copy(), A.copy(), float(g[name + '/alpha']),
+                                tol=float(g[name + '/tol']), method=method,
+                                maxiter=int(g[name + '/maxiter']),
+                                mask=None if mask is None else mask.copy())
+            xr = g[name + '/x']
+            assert x.shape == xr.shape and x.dtype == y.dtype, name
+            if kind == 'f32':
+                assert _err(x, xr) < 1e-3, (name, _err(x, xr))
+                if tag == 'exh':
+                    assert it == int(g[name + '/it']), name
+            else:
+                assert it == int(g[name + '/it']), (name, it, int(g[name + '/it']))
+                assert _err(x, xr) < 1e-8, (name, _err(x, xr))
+
+
+def test_prox_known_answers_public_helpers():
+    """tests/test_lasso.py:15-56 hand values on the public helper functions."""
+    from decomp_amd import lasso
+    assert np.allclose(lasso.soft_threshold_float(np.array([0.1, -2.0, 1.4]), 1.0), [0.0, -1.0, 0.4])
+    z = np.array([0.1, -2.0, 1.4])
+    assert np.allclose(lasso.soft_threshold_complex(z * 1.0j, 1.0),
+                       lasso.soft_threshold_complex(z + 0j, 1.0) * 1.0j)
+    assert np.allclose(lasso.soft_threshold_positive(z, 1.0), [0.0, 0.0, 0.4])
+
+
+@pytest.mark.parametrize('method', ['ista', 'acc_ista', 'fista', 'cd', 'ista_pos', 'cd_pos'])
+@pytest.mark.parametrize('dt', ['float32', 'float64', 'complex64'])
+def test_against_oracle_medium(method, dt):
+    """2048 x 384, K = 192 (exercises the MFMA path for float32, multi-tile generic path
+    otherwise): 30 iterations, no early stop, same iterate as the oracle."""
+    from decomp_amd import lasso
+    from oracle import lasso as olasso
+    if dt == 'complex64' and method.endswith('_pos'):
+        pytest.skip('positive solvers are real only')
+    rng = np.random.RandomState(3)
+    N, F, K = 2048, 384, 192
+    if method.startswith('cd'):      # the oracle's as-written CD costs K times more: keep it small
+        N, F, K = 300, 96, 80
+    cplx = dt == 'complex64'
+
+    def randn(*s):
+        return (rng.randn(*s) + 1j * rng.randn(*s)) if cplx else rng.randn(*s)
+    A = randn(K, F)
+    xt = randn(N, K) * (rng.uniform(size=(N, K)) < 0.05)
+    y = xt @ A + 0.1 * randn(N, F)
+    A, y = A.astype(dt), y.astype(dt)
+    alpha = 0.05
+    it, x = lasso.solve(y, A, alpha, tol=1e-9, method=method, maxiter=30)
+    ito, xo = olasso.solve(y.copy(), A.copy(), alpha, tol=1e-9, method=method, maxiter=30)
+    if method.startswith('cd') and dt != 'float64':
+        # the Gram-form sweep can reach a bit-exact fixed point (all dx == 0) in fp32 where the
+        # reference's recomputed-residual form keeps jittering by an ulp: it stops at a check
+        assert it in (0, 10, 20, 29), it
+    else:
+        assert it == ito
+    tol = 2e-4 if dt != 'float64' else 1e-9
+    assert _err(x, xo) < tol, _err(x, xo)
+    assert np.count_nonzero(x) > 0
+
+
+def test_mask_equivalences():
+    """tests/test_lasso.py:185-226: all-ones mask == no mask; 1-D mask == tiled 2-D mask."""
+    from decomp_amd import lasso
+    rng = np.random.RandomState(0)
+    A = rng.randn(5, 10)
+    xt = (rng.randn(55) * np.rint(rng.uniform(size=55))).reshape(11, 5)
+    y = xt @ A + rng.randn(11, 10) * 0.1
+    for method in ['ista', 'acc_ista', 'fista', 'cd']:
+        _, x0 = lasso.solve(y, A, alpha=0.1, tol=1e-6, method=method, maxiter=1000)
+        _, x1 = lasso.solve(y, A, alpha=0.1, tol=1e-6, method=method, maxiter=1000,
+                            mask=np.ones(y.shape))
+        assert np.allclose(x0, x1, atol=1e-6), method
+        m1 = np.rint(rng.uniform(0.4, 1.0, size=10))
+        it, xa = lasso.solve(y, A, alpha=0.1, tol=1e-6, method=method, maxiter=1000, mask=m1)
+        assert it < 999
+        _, xb = lasso.solve(y, A, alpha=0.1, tol=1e-6, method=method, maxiter=1000,
+                            mask=np.ones(y.shape) * m1)
+        assert np.allclose(xa, xb, atol=1e-5, rtol=1e-3), method
+
+
+def test_errors_and_unsupported_methods():
+    from decomp_amd import lasso
+    y, A = np.random.randn(4, 6), np.random.randn(3, 6)
+    with pytest.raises(NotImplementedError):
+        lasso.solve(y, A, 0.1, method='admm')
+    with pytest.raises(NotImplementedError):
+        lasso.solve(y, A, 0.1, method='parallel_cd')
+    with pytest.raises(AssertionError):        # negative mask (lasso.py:78)
+        lasso.solve(y, A, 0.1, mask=-np.ones((4, 6)))
+    with pytest.raises(AssertionError):        # complex + _pos (lasso.py:92)
+        lasso.solve(y.astype(complex), A.astype(complex), 0.1, method='ista_pos')
+    # maxiter exhaustion returns maxiter - 1
+    it, x = lasso.solve(y, A, 0.1, tol=0.0, maxiter=13, method='fista')
+    assert it == 12
