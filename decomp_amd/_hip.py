@@ -48,6 +48,22 @@ SIGNATURES = {
     'dcp_lasso_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_int, _P(_c_int)]),
     'dcp_lasso_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_int, _P(_c_int)]),
     'dcp_lasso_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_int, _P(_c_int)]),
+    'dcp_dict_stats_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
+    'dcp_dict_update_f32': (_c_int, [_c_vp, _c_vp, _c_f64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_dict_step_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_gather_rows_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_dict_stats_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
+    'dcp_dict_update_f64': (_c_int, [_c_vp, _c_vp, _c_f64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_dict_step_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_gather_rows_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_dict_stats_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
+    'dcp_dict_update_c64': (_c_int, [_c_vp, _c_vp, _c_f64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_dict_step_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_gather_rows_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_dict_stats_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
+    'dcp_dict_update_c128': (_c_int, [_c_vp, _c_vp, _c_f64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_dict_step_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_gather_rows_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_nmf_mu_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                                 _c_int, _c_f32, _c_int, _P(_c_int), _P(_c_f32), _P(_c_f32)]),
     'dcp_nmf_mu_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,

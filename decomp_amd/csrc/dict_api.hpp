@@ -1,0 +1,142 @@
+// C-ABI glue for the dictionary-learning step.
+#pragma once
+#include "dict_impl.hpp"
+#include "lasso_api.hpp"
+
+namespace dcp {
+
+template <class T>
+inline void dict_plan_extra(WsPlan& p, int64_t Nb, int64_t F, int64_t K) {
+    typedef real_t<T> R;
+    p.add<T>(dict_slab_elems<T>(Nb, F, K));
+    p.add<R>((size_t)2 * ((F + 63) / 64) + 512);
+    p.add<R>(4);
+}
+template <class T>
+inline int dict_carve_extra(dcp_handle* h, DictWs<T>& w, int64_t Nb, int64_t F, int64_t K) {
+    typedef real_t<T> R;
+    w.slab_count = dict_slab_elems<T>(Nb, F, K);
+    w.slabs = ws_alloc<T>(h, w.slab_count);
+    w.partial = ws_alloc<R>(h, (size_t)2 * ((F + 63) / 64) + 512);
+    w.scal = ws_alloc<R>(h, 4);
+    if (!w.slabs || !w.partial || !w.scal) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
+    return DCP_OK;
+}
+
+template <class T>
+inline int dict_check(dcp_handle* h, const void* a, const void* b, const void* c, int64_t Nb, int64_t F,
+                      int64_t K) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!a || !b || !c) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (Nb <= 0 || F <= 0 || K <= 0) return fail(h, DCP_ERR_INVALID, "sizes must be positive");
+    if (Nb > 0x7fffffffLL || F + K > 0x3fffffffLL) return fail(h, DCP_ERR_INVALID, "dimension too large");
+    return DCP_OK;
+}
+
+// lasso on this rank's minibatch rows + local x^H [y | x]
+template <class T>
+inline int dict_stats_core(dcp_handle* h, const T* Y, T* X, const T* D, int64_t Nb, int64_t F, int64_t K,
+                           double alpha, int lasso_method, int lasso_iter, double lasso_tol, T* stats,
+                           int* lasso_it, LassoWs<T>& lw, DictWs<T>& dw) {
+    typedef real_t<T> R;
+    int it = 0;
+    if constexpr (scalar_traits<T>::is_complex) {
+        DCP_TRY((lasso_solve<T, PROX_COMPLEX>(h, Y, (const R*)nullptr, 0, D, X, Nb, F, K, (R)alpha,
+                                              (R)lasso_tol, lasso_iter, lasso_method, &it, lw)));
+    } else {
+        DCP_TRY((lasso_solve<T, PROX_REAL>(h, Y, (const R*)nullptr, 0, D, X, Nb, F, K, (R)alpha,
+                                           (R)lasso_tol, lasso_iter, lasso_method, &it, lw)));
+    }
+    if (lasso_it) *lasso_it = it;
+    return dict_local_stats<T>(h, Y, X, Nb, F, K, stats, dw);
+}
+
+template <class T>
+inline int dict_stats_api(dcp_handle* h, const T* Y, T* X, const T* D, int64_t Nb, int64_t F, int64_t K,
+                          double alpha, int lasso_method, int lasso_iter, double lasso_tol, T* stats,
+                          int* lasso_it) {
+    DCP_TRY(dict_check<T>(h, Y, X, D, Nb, F, K));
+    if (!stats) return fail(h, DCP_ERR_INVALID, "stats is null");
+    if (lasso_method < DCP_LASSO_ISTA || lasso_method > DCP_LASSO_CD)
+        return fail(h, DCP_ERR_INVALID, "bad lasso method");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    WsPlan plan;
+    lasso_plan<T>(plan, Nb, F, K, 0, lasso_method);
+    dict_plan_extra<T>(plan, Nb, F, K);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    LassoWs<T> lw;
+    DictWs<T> dw;
+    DCP_TRY(lasso_carve<T>(h, lw, Nb, F, K, 0, lasso_method));
+    DCP_TRY(dict_carve_extra<T>(h, dw, Nb, F, K));
+    return dict_stats_core<T>(h, Y, X, D, Nb, F, K, alpha, lasso_method, lasso_iter, lasso_tol, stats,
+                              lasso_it, lw, dw);
+}
+
+template <class T>
+inline int dict_update_api(dcp_handle* h, const T* stats, double beta, T* A, T* B, const T* D, T* Dnew,
+                           int64_t F, int64_t K, real_t<T>* maxdiff_dev) {
+    typedef real_t<T> R;
+    if (!h) return DCP_ERR_INVALID;
+    if (!stats || !A || !B || !D || !Dnew || !maxdiff_dev) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (F <= 0 || K <= 0) return fail(h, DCP_ERR_INVALID, "sizes must be positive");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    WsPlan plan;
+    plan.add<R>((size_t)2 * ((F + 63) / 64) + 512);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    DictWs<T> dw;
+    dw.partial = ws_alloc<R>(h, (size_t)2 * ((F + 63) / 64) + 512);
+    if (!dw.partial) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
+    return dict_update<T>(h, stats, (R)beta, A, B, D, Dnew, F, K, maxdiff_dev, dw);
+}
+
+// dictionary_learning.py:137-164 for one minibatch on one GPU.
+template <class T>
+inline int dict_step_api(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, T* A, T* B, int64_t Nb,
+                         int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                         int lasso_iter, double lasso_tol, double* maxdiff_host, int* lasso_it) {
+    typedef real_t<T> R;
+    DCP_TRY(dict_check<T>(h, Y, X, D, Nb, F, K));
+    if (!Dnew || !A || !B || !maxdiff_host) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (lasso_method < DCP_LASSO_ISTA || lasso_method > DCP_LASSO_CD)
+        return fail(h, DCP_ERR_INVALID, "bad lasso method");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    WsPlan plan;
+    lasso_plan<T>(plan, Nb, F, K, 0, lasso_method);
+    dict_plan_extra<T>(plan, Nb, F, K);
+    plan.add<T>((size_t)K * (F + K));
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    LassoWs<T> lw;
+    DictWs<T> dw;
+    DCP_TRY(lasso_carve<T>(h, lw, Nb, F, K, 0, lasso_method));
+    DCP_TRY(dict_carve_extra<T>(h, dw, Nb, F, K));
+    T* stats = ws_alloc<T>(h, (size_t)K * (F + K));
+    if (!stats) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
+    DCP_TRY(dict_stats_core<T>(h, Y, X, D, Nb, F, K, alpha, lasso_method, lasso_iter, lasso_tol, stats,
+                               lasso_it, lw, dw));
+    DCP_TRY(dict_update<T>(h, stats, (R)beta, A, B, D, Dnew, F, K, dw.scal, dw));
+    void* hostv = nullptr;
+    DCP_TRY(host_scratch(h, 64, &hostv));
+    DCP_HIP_OK(h, hipMemcpyAsync(hostv, dw.scal, sizeof(R), hipMemcpyDeviceToHost, h->stream));
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    *maxdiff_host = (double)(*reinterpret_cast<R*>(hostv));
+    return DCP_OK;
+}
+
+template <class T>
+inline int gather_rows_api(dcp_handle* h, const T* in, const long long* index, int64_t rows, int64_t cols,
+                           T* out) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!in || !index || !out) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (rows < 0 || cols < 0) return fail(h, DCP_ERR_INVALID, "negative size");
+    if (rows == 0 || cols == 0) return DCP_OK;
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(grid_for((long)rows * cols, 4096)), dim3(256), 0,
+                       h->stream, in, index, (long)rows, (long)cols, out);
+    DCP_HIP_OK(h, hipGetLastError());
+    return DCP_OK;
+}
+
+}  // namespace dcp

@@ -167,6 +167,67 @@ int dcp_lasso_c128(dcp_handle* h, const void* Y, const double* mask, int mask_nd
                    void* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
                    int method, int positive, int* it_out);
 
+/* ---- online dictionary learning (block coordinate descent) -------------------------- */
+/* One minibatch step of decomp/dictionary_learning.py:135-164 (solve_cd), split at the
+ * data-parallel exchange point like the NMF step:
+ *   dcp_dict_stats_*  : x_mb <- lasso.solve_fastpath(y_mb, D, alpha, x_mb, lasso_tol,
+ *                       lasso_iter, lasso_method) (in place), then this rank's
+ *                       stats[K, F+K] = x_mb^H [ y_mb | x_mb ]   (lines 137-152)
+ *   dcp_dict_update_* : A <- beta A + stats[:, F:], B <- beta B + stats[:, :F] (147-152),
+ *                       the sequential atom sweep into D_new (154-159), and max|D - D_new|
+ *                       into the DEVICE scalar maxdiff_dev (161).  Asynchronous.
+ *   dcp_dict_step_*   : both on one GPU; max|D - D_new| returned to the HOST double.
+ * D [K,F] must be l2_strict-normalised by the caller on entry of the run (line 126); A [K,K]
+ * and B [K,F] are the running statistics (zero before the first step). */
+int dcp_dict_stats_f32(dcp_handle* h, const float* Y, float* X, const float* D, int64_t Nb, int64_t F,
+                        int64_t K, double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                        float* stats, int* lasso_it);
+int dcp_dict_update_f32(dcp_handle* h, const float* stats, double beta, float* A, float* B, const float* D,
+                         float* D_new, int64_t F, int64_t K, float* maxdiff_dev);
+int dcp_dict_step_f32(dcp_handle* h, const float* Y, float* X, const float* D, float* D_new, float* A, float* B,
+                       int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                       int lasso_iter, double lasso_tol, double* maxdiff, int* lasso_it);
+/* out[i, :] = in[index[i], :]  (MinibatchData.shuffle / .array, decomp/utils/data.py:147-156);
+ * index: int64 on the device. */
+int dcp_gather_rows_f32(dcp_handle* h, const float* in, const int64_t* index, int64_t rows,
+                         int64_t cols, float* out);
+int dcp_dict_stats_f64(dcp_handle* h, const double* Y, double* X, const double* D, int64_t Nb, int64_t F,
+                        int64_t K, double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                        double* stats, int* lasso_it);
+int dcp_dict_update_f64(dcp_handle* h, const double* stats, double beta, double* A, double* B, const double* D,
+                         double* D_new, int64_t F, int64_t K, double* maxdiff_dev);
+int dcp_dict_step_f64(dcp_handle* h, const double* Y, double* X, const double* D, double* D_new, double* A, double* B,
+                       int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                       int lasso_iter, double lasso_tol, double* maxdiff, int* lasso_it);
+/* out[i, :] = in[index[i], :]  (MinibatchData.shuffle / .array, decomp/utils/data.py:147-156);
+ * index: int64 on the device. */
+int dcp_gather_rows_f64(dcp_handle* h, const double* in, const int64_t* index, int64_t rows,
+                         int64_t cols, double* out);
+int dcp_dict_stats_c64(dcp_handle* h, const void* Y, void* X, const void* D, int64_t Nb, int64_t F,
+                        int64_t K, double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                        void* stats, int* lasso_it);
+int dcp_dict_update_c64(dcp_handle* h, const void* stats, double beta, void* A, void* B, const void* D,
+                         void* D_new, int64_t F, int64_t K, float* maxdiff_dev);
+int dcp_dict_step_c64(dcp_handle* h, const void* Y, void* X, const void* D, void* D_new, void* A, void* B,
+                       int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                       int lasso_iter, double lasso_tol, double* maxdiff, int* lasso_it);
+/* out[i, :] = in[index[i], :]  (MinibatchData.shuffle / .array, decomp/utils/data.py:147-156);
+ * index: int64 on the device. */
+int dcp_gather_rows_c64(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
+                         int64_t cols, void* out);
+int dcp_dict_stats_c128(dcp_handle* h, const void* Y, void* X, const void* D, int64_t Nb, int64_t F,
+                        int64_t K, double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                        void* stats, int* lasso_it);
+int dcp_dict_update_c128(dcp_handle* h, const void* stats, double beta, void* A, void* B, const void* D,
+                         void* D_new, int64_t F, int64_t K, double* maxdiff_dev);
+int dcp_dict_step_c128(dcp_handle* h, const void* Y, void* X, const void* D, void* D_new, void* A, void* B,
+                       int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                       int lasso_iter, double lasso_tol, double* maxdiff, int* lasso_it);
+/* out[i, :] = in[index[i], :]  (MinibatchData.shuffle / .array, decomp/utils/data.py:147-156);
+ * index: int64 on the device. */
+int dcp_gather_rows_c128(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
+                         int64_t cols, void* out);
+
 #ifdef __cplusplus
 }
 #endif

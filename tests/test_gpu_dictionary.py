@@ -1,0 +1,129 @@
+"""GPU parity: decomp_amd.dictionary_learning (HIP, through the C ABI) against the golden
+vectors of the real reference (tests/test_dictionary.py shapes, real and complex, every
+starred lasso method, 1-3 epochs with the exact RandomState shuffle) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _g():
+    return np.load(os.path.join(GOLDEN, 'dl_golden.npz'), allow_pickle=False)
+
+
+def _err(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) / max(1.0, float(np.max(np.abs(b))))
+
+
+def _cases():
+    g = _g()
+    return [str(c) for c in g['cases'] if '/mask/' not in str(c)]
+
+
+@pytest.mark.parametrize('name', _cases())
+def test_golden(name):
+    from decomp_amd import dictionary_learning as dl
+    g = _g()
+    parts = name.split('/')
+    base = parts[0]
+    y, D0 = g[base + '/y'], g[base + '/D0']
+    if parts[1] == 'reftest':
+        it, D, x = dl.solve(y.copy(), D0.copy(), 0.1, tol=1.0e-4, minibatch=100, maxiter=1000,
+                            lasso_method='acc_ista', lasso_iter=1000, random_seed=0)
+    else:
+        minibatch = int(parts[1][2:])
+        lm = parts[2].rstrip('0123456789')
+        li = int(parts[2][len(lm):])
+        epochs = int(parts[4][2:])
+        it, D, x = dl.solve(y.copy(), D0.copy(), 0.1, tol=0.0, minibatch=minibatch,
+                            maxiter=epochs + 1, lasso_method=lm, lasso_iter=li,
+                            lasso_tol=1.0e-5, random_seed=0)
+    assert it == int(g[name + '/it']), name
+    assert D.dtype == y.dtype and x.shape == (101, 3)
+    assert _err(D, g[name + '/D']) < 1e-7, (name, _err(D, g[name + '/D']))
+    assert _err(x, g[name + '/x']) < 1e-7, (name, _err(x, g[name + '/x']))
+
+
+@pytest.mark.parametrize('dt', ['float32', 'complex64'])
+@pytest.mark.parametrize('lm', ['ista', 'cd'])
+def test_against_oracle_medium(dt, lm):
+    """1024 x 256, K = 64, minibatch 256, 2 epochs: float32 / complex64 (MFMA path for
+    float32) against the CPU oracle."""
+    from decomp_amd import dictionary_learning as dl
+    from oracle import dictionary_learning as odl
+    rng = np.random.RandomState(2)
+    N, F, K = 1024, 256, 64
+    cplx = dt == 'complex64'
+
+    def randn(*s):
+        return (rng.randn(*s) + 1j * rng.randn(*s)) if cplx else rng.randn(*s)
+    Dt = randn(K, F)
+    xt = 3.0 * randn(N, K) * (rng.uniform(size=(N, K)) < 0.1)
+    y = (xt @ Dt + 0.1 * randn(N, F)).astype(dt)
+    D0 = (Dt + 0.2 * randn(K, F)).astype(dt)
+    kw = dict(tol=0.0, minibatch=256, maxiter=3, lasso_method=lm, lasso_iter=10,
+              lasso_tol=1e-5, random_seed=0)
+    it, D, x = dl.solve(y.copy(), D0.copy(), 0.01, **kw)
+    ito, Do, xo = odl.solve(y.copy(), D0.copy(), 0.01, **kw)
+    assert it == ito == 3
+    assert _err(D, Do) < 5e-4, _err(D, Do)
+    assert _err(x, xo) < 5e-3, _err(x, xo)
+    assert np.count_nonzero(x) > 0
+
+
+def test_reference_property_minimum():
+    """tests/test_dictionary.py:45-56: converges, and the loss at the solution is below the
+    loss at random perturbations of it."""
+    from decomp_amd import dictionary_learning as dl
+    from oracle.common import l2
+    g = _g()
+    y, D0 = g['dl_f64/y'], g['dl_f64/D0']
+    alpha = 0.1
+    it, D, x = dl.solve(y, D0.copy(), alpha, x=None, tol=1.0e-4, minibatch=100, maxiter=1000,
+                        lasso_method='acc_ista', lasso_iter=1000, random_seed=0)
+    assert it < 999 and not np.allclose(x, 0)
+
+    def loss(x, D):
+        a = alpha * y.shape[1]
+        return np.sum(0.5 / a * np.abs(y - x @ l2(D)) ** 2) + np.sum(np.abs(x))
+    rng = np.random.RandomState(0)
+    base = loss(x, D)
+    for _ in range(3):
+        assert base < loss(x + rng.randn(*x.shape) * 1e-3, D + rng.randn(*D.shape) * 1e-3)
+
+
+def test_minibatch_container_roundtrip():
+    """tests/test_utils.py: shuffle is cumulative, .array restores the original order, tail
+    rows are skipped by the iteration."""
+    import torch
+    from decomp_amd.utils.data import MinibatchData
+    a = np.arange(23 * 3, dtype=np.float64).reshape(23, 3)
+    mb = MinibatchData(torch.from_numpy(a).cuda(), 5)
+    assert mb.n_loop == 4
+    rng = np.random.RandomState(0)
+    idx = np.arange(23)
+    ref = a.copy()
+    for _ in range(3):
+        rng.shuffle(idx)
+        mb.shuffle(idx)
+        ref = ref[idx]
+        blocks = [b.cpu().numpy() for b in mb]
+        assert len(blocks) == 4 and np.array_equal(np.concatenate(blocks), ref[:20])
+        assert np.array_equal(mb.array.cpu().numpy(), a)
+    with pytest.raises(ValueError):
+        MinibatchData(torch.zeros((3, 2)).cuda(), 5)
+
+
+def test_errors():
+    from decomp_amd import dictionary_learning as dl
+    y, D = np.random.randn(20, 5), np.random.randn(3, 5)
+    with pytest.raises(NotImplementedError):
+        dl.solve(y, D, 0.1)                                  # minibatch is required
+    with pytest.raises(NotImplementedError):
+        dl.solve(y, D, 0.1, minibatch=10, method='parallel_cd')
+    with pytest.raises(ValueError):
+        dl.solve(y, D, 0.1, minibatch=50)                    # minibatch > n_samples
