@@ -103,6 +103,9 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rows', type=int, default=0,
+                    help='(analysis only) rows of Y on this GPU instead of 65536/N: time one '
+                         'shard of a larger run without the collective')
     args = ap.parse_args()
 
     import torch
@@ -124,8 +127,11 @@ def main():
                                 device_id=device)
 
     rows = N_ROWS // world
+    if args.rows:
+        rows = args.rows
     Y, D0 = synth(rows, rank, device)
     x = torch.ones((rows, N_ATOMS), dtype=torch.float32, device=device)
+    state = {'x': x}
     D = D0.clone()
     _arrays.l2_normalize_(D, strict=True)
     torch.cuda.synchronize()
@@ -148,10 +154,11 @@ def main():
             _hip.check(h, rc, 'dcp_nmf_mu_f32')
             assert it.value == n_steps + 1
             return D
-        backend = sharded.HipStepBackend(Y, None, x, D, _hip.LIK_L2)
+        backend = sharded.HipStepBackend(Y, None, state['x'], D, _hip.LIK_L2)
         it, Dout = sharded.mu_loop(backend, D, 0.0, n_steps + 1, world_size=world,
                                    new_like=torch.empty_like)
         assert it == n_steps + 1
+        state['x'] = backend.x
         return Dout
 
     Dcur = run(args.warmup)
@@ -180,7 +187,7 @@ def main():
             prof[lib.dcp_profile_label_name(lab).decode()] = {
                 'ms_total': ms.value, 'launches': cnt.value, 'ms_avg': ms.value / cnt.value}
 
-    finite = bool(torch.isfinite(Dcur).all().item()) and bool(torch.isfinite(x).all().item())
+    finite = bool(torch.isfinite(Dcur).all().item()) and bool(torch.isfinite(state['x']).all().item())
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -190,7 +197,8 @@ def main():
             'unit': 'iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'nmf_mu l2 no-mask Y=65536x4096 k=256 fp32 (BASELINE configs[1])',
+            'config': {'workload': ('nmf_mu l2 no-mask Y=65536x4096 k=256 fp32 (BASELINE configs[1])'
+                                    if not args.rows else 'ANALYSIS ONLY: one shard of %d rows' % rows),
                        'rows_per_gpu': rows, 'parallelism': 'rows sharded x%d, 1 all-reduce/step' % world},
             'algorithmic_tflops': W / (elapsed / args.steps) / 1e12,
             'mfma_roofline_frac_whole_step': W / (elapsed / args.steps) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),

@@ -69,14 +69,14 @@ SIGNATURES = {
     'dcp_nmf_mu_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                                 _c_int, _c_f64, _c_int, _P(_c_int), _P(_c_f64), _P(_c_f64)]),
     'dcp_nmf_mu_stats_width': (_c_i64, [_c_i64, _c_i64, _c_int, _c_int]),
-    'dcp_nmf_mu_stats_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
-                                      _c_int, _c_vp]),
-    'dcp_nmf_mu_stats_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
-                                      _c_int, _c_vp]),
+    'dcp_nmf_mu_stats_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64,
+                                      _c_i64, _c_int, _c_vp]),
+    'dcp_nmf_mu_stats_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64,
+                                      _c_i64, _c_int, _c_vp]),
     'dcp_nmf_mu_update_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_int,
-                                       _c_int, _c_vp]),
+                                       _c_int, _c_vp, _c_vp]),
     'dcp_nmf_mu_update_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_int,
-                                       _c_int, _c_vp]),
+                                       _c_int, _c_vp, _c_vp]),
     'dcp_nmf_residual_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                                       _P(_c_f64)]),
     'dcp_nmf_residual_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,

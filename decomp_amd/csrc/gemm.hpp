@@ -15,7 +15,7 @@ namespace dcp {
 //   NT: C[M,N] = A[M,K] . B[N,K]^T(H)      NN: C[M,N] = A[M,K] . B[K,N]
 //   TN: C[M,N] = A[K,M]^T(H) . B[K,N]
 enum GemmForm { FORM_NT = 0, FORM_NN = 1, FORM_TN = 2 };
-enum TileSel { TILE_AUTO = 0, TILE_LARGE = 1, TILE_SMALL = 2 };
+enum TileSel { TILE_AUTO = 0, TILE_LARGE = 1, TILE_SMALL = 2, TILE_HUGE = 3 };
 
 template <class T>
 struct GemmArgs {
@@ -33,32 +33,43 @@ struct GemmArgs {
     int tile = TILE_AUTO;
 };
 
-// MFMA tile configurations (BM, BN, BK, WM, WN, min waves/SIMD)
-typedef TileCfg<128, 128, 16, 64, 64, 2> CfgLargeNT;   // 64 acc regs/lane -> up to 4 WG/CU
-typedef TileCfg<128, 128, 16, 64, 64, 2> CfgLargeNN;
-typedef TileCfg<128, 128, 16, 64, 64, 2> CfgLargeTN;
+// MFMA tile tiers (BM, BN, BK, WM, WN, min waves/SIMD).  Measured on MI355X (tools/gemm_sweep.py,
+// Y.D^T at 65536x4096x256): 256x256 / 16 waves 139 TF, 128x128 / 4 waves 110 TF -- the big tile
+// halves the operand traffic per flop and one workgroup per CU is exactly one round.  The
+// reduction-over-samples form (TN) is insensitive to the tile (131 TF either way) and keeps
+// 128x128, whose 68 tiles x 15 splits fill one round of 1024 resident workgroups.
+typedef TileCfg<256, 256, 16, 64, 64, 1> CfgHuge;      // 16 waves, 64 KiB LDS
+typedef TileCfg<128, 128, 16, 64, 64, 2> CfgLarge;     // 4 waves, 32 KiB LDS -> 4 WG/CU
 typedef TileCfg<64, 64, 16, 32, 32, 2> CfgSmall;
 
-template <int FORM> struct LargeCfgOf;
-template <> struct LargeCfgOf<FORM_NT> { typedef CfgLargeNT type; };
-template <> struct LargeCfgOf<FORM_NN> { typedef CfgLargeNN type; };
-template <> struct LargeCfgOf<FORM_TN> { typedef CfgLargeTN type; };
+enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2 };
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
-// Tile footprint the float path will use for this problem (needed to plan split-K
-// before the launch).  Large tiles when they alone give the chip enough workgroups.
+inline void tier_dims(int tier, int& bm, int& bn) {
+    if (tier == TIER_HUGE) { bm = CfgHuge::BM; bn = CfgHuge::BN; }
+    else if (tier == TIER_LARGE) { bm = CfgLarge::BM; bn = CfgLarge::BN; }
+    else { bm = 64; bn = 64; }
+}
+
+// The tile tier the float path uses for this problem (split-K planning needs it before the
+// launch): the largest tile that still gives the chip enough workgroups, counting the splits
+// a deep reduction allows.
 template <int FORM>
-inline bool use_small_tile(int M, int N, int K, int tile_sel) {
-    if (tile_sel == TILE_LARGE) return false;
-    if (tile_sel == TILE_SMALL) return true;
-    typedef typename LargeCfgOf<FORM>::type L;
-    const long wgs_large = (long)ceil_div(M, L::BM) * ceil_div(N, L::BN);
-    // a deep reduction can still fill the chip with large tiles through split-K
+inline int pick_tier(int M, int N, int K, int tile_sel) {
+    if (tile_sel == TILE_SMALL) return TIER_SMALL;
+    if (tile_sel == TILE_LARGE) return TIER_LARGE;
+    if (tile_sel == TILE_HUGE) return FORM == FORM_TN ? TIER_LARGE : TIER_HUGE;
     long splits = K / 512;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
-    return wgs_large * splits < 256;
+    if (FORM != FORM_TN) {
+        const long wh = (long)ceil_div(M, CfgHuge::BM) * ceil_div(N, CfgHuge::BN);
+        if (M >= 256 && N >= 256 && wh * splits >= 192) return TIER_HUGE;
+    }
+    const long wl = (long)ceil_div(M, CfgLarge::BM) * ceil_div(N, CfgLarge::BN);
+    if (wl * splits >= 256) return TIER_LARGE;
+    return TIER_SMALL;
 }
 
 // Choose split-K so that the grid reaches ~target workgroups, each split a multiple
@@ -66,17 +77,17 @@ inline bool use_small_tile(int M, int N, int K, int tile_sel) {
 template <int FORM, class T>
 inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits) {
     int bm = 64, bn = 64;
-    if (std::is_same<T, float>::value && !use_small_tile<FORM>(a.M, a.N, a.K, a.tile)) {
-        typedef typename LargeCfgOf<FORM>::type L;
-        bm = L::BM;
-        bn = L::BN;
-    }
+    if (std::is_same<T, float>::value) tier_dims(pick_tier<FORM>(a.M, a.N, a.K, a.tile), bm, bn);
     const int n1 = a.B2 != nullptr ? a.n_b1 : a.N;
     const long tiles = (long)ceil_div(a.M, bm) * (ceil_div(n1, bn) + ceil_div(a.N - n1, bn));
-    long s = tiles > 0 ? target_wgs / tiles : 1;  // floor: stay within `target` resident slots
-    if (s > max_splits) s = max_splits;
     const long kblocks = ceil_div(a.K > 0 ? a.K : 1, 16);
-    if (s > kblocks) s = kblocks;
+    // splits allowed by the reduction depth: keep every split at least 512 deep (32 K blocks)
+    // so that tile prologue / slab write-out stay small against the MFMA work
+    long smax = kblocks / 32;
+    if (smax < 1) smax = 1;
+    if (smax > max_splits) smax = max_splits;
+    long s = tiles > 0 ? target_wgs / tiles : 1;  // floor: stay within `target` resident slots
+    if (s > smax) s = smax;
     if (s < 1) s = 1;
     const long blocks_per_split = (kblocks + s - 1) / s;
     a.klen = (int)(blocks_per_split * 16);
@@ -97,9 +108,12 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
         constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
         constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
-        if (use_small_tile<FORM>(a.M, a.N, a.K, a.tile))
-            return launch_gemm_mfma<CfgSmall, AL, BL, Epi>(stream, p, epi);
-        return launch_gemm_mfma<typename LargeCfgOf<FORM>::type, AL, BL, Epi>(stream, p, epi);
+        const int tier = pick_tier<FORM>(a.M, a.N, a.K, a.tile);
+        if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL, Epi>(stream, p, epi);
+        if constexpr (FORM != FORM_TN) {
+            if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL, Epi>(stream, p, epi);
+        }
+        return launch_gemm_mfma<CfgLarge, AL, BL, Epi>(stream, p, epi);
     } else {
         GenericProblem<T> p;
         p.A = a.A; p.B = a.B; p.B2 = a.B2; p.n_b1 = a.n_b1;

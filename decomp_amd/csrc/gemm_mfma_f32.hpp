@@ -60,6 +60,8 @@ struct GemmProblem {
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_>
 struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_;
+    static constexpr int NWAVES = (BM_ / WM_) * (BN_ / WN_);
+    static constexpr int NTHREADS = 64 * NWAVES;
 };
 
 // blocks b and b+8 share an XCD (round-robin dispatch).  Give every XCD a
@@ -72,7 +74,7 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return base + within;
 }
 
-template <int LAY, int ROWS, int BK>
+template <int LAY, int ROWS, int BK, int NT = 256>
 struct PanelGeom {
     static constexpr int STRIDE = (LAY == KMAJOR) ? BK : ROWS;
     static constexpr int CHUNKS = BK / 4;   // 16-byte chunks per KMAJOR row
@@ -84,19 +86,19 @@ struct PanelGeom {
     }
     static constexpr int LINES = (LAY == KMAJOR) ? ROWS : BK;
     static constexpr int ELEMS = STRIDE * LINES;
-    static constexpr int F4 = ROWS * BK / 4 / 256;  // float4 per thread per block
-    static_assert(ROWS * BK % 1024 == 0, "panel must be a multiple of 256 float4");
+    static constexpr int F4 = ROWS * BK / 4 / NT;  // float4 per thread per block
+    static_assert(ROWS * BK % (4 * NT) == 0, "panel must be a whole number of float4 per thread");
 };
 
 // Loads one panel block into registers.  EDGE: scalar, predicated, any alignment.
-template <int LAY, int ROWS, int BK, bool EDGE, int F4>
+template <int LAY, int ROWS, int BK, bool EDGE, int NT, int F4>
 __device__ __forceinline__ void panel_gload(f32x4 (&r)[F4],
                                             const float* __restrict__ p, long ld, int row0,
                                             int nrows, int k0, int kend, int tid) {
-    static_assert(F4 == PanelGeom<LAY, ROWS, BK>::F4, "register panel size");
+    static_assert(F4 == PanelGeom<LAY, ROWS, BK, NT>::F4, "register panel size");
 #pragma unroll
     for (int i = 0; i < F4; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NT;
         if (LAY == KMAJOR) {
             const int row = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
             const float* src = p + (long)(row0 + row) * ld + (k0 + kq);
@@ -123,13 +125,13 @@ __device__ __forceinline__ void panel_gload(f32x4 (&r)[F4],
     }
 }
 
-template <int LAY, int ROWS, int BK, int F4>
+template <int LAY, int ROWS, int BK, int NT, int F4>
 __device__ __forceinline__ void panel_lds_store(float* s, const f32x4 (&r)[F4], int tid) {
-    static_assert(F4 == PanelGeom<LAY, ROWS, BK>::F4, "register panel size");
+    static_assert(F4 == PanelGeom<LAY, ROWS, BK, NT>::F4, "register panel size");
     constexpr int STRIDE = PanelGeom<LAY, ROWS, BK>::STRIDE;
 #pragma unroll
     for (int i = 0; i < F4; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NT;
         if (LAY == KMAJOR) {
             const int row = idx / (BK / 4), q = idx % (BK / 4);
             *reinterpret_cast<f32x4*>(s + PanelGeom<LAY, ROWS, BK>::kchunk(row, q)) = r[i];
@@ -158,14 +160,14 @@ __device__ __forceinline__ f32x4 panel_frag(const float* s, int row, int c, int 
 }
 
 template <class Cfg, int ALAY, int BLAY, bool EDGE, class Epi>
-__global__ void __launch_bounds__(256, Cfg::MINW) gemm_mfma_kernel(GemmProblem p, Epi epi) {
+__global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(GemmProblem p, Epi epi) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, WM = Cfg::WM, WN = Cfg::WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    constexpr int NT = Cfg::NTHREADS;
     static_assert(BK % 8 == 0, "BK multiple of 8");
-    typedef PanelGeom<ALAY, BM, BK> GA;
-    typedef PanelGeom<BLAY, BN, BK> GB;
+    typedef PanelGeom<ALAY, BM, BK, NT> GA;
+    typedef PanelGeom<BLAY, BN, BK, NT> GB;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (GA::ELEMS + GB::ELEMS)];
     float* sA0 = smem;
@@ -222,10 +224,10 @@ __global__ void __launch_bounds__(256, Cfg::MINW) gemm_mfma_kernel(GemmProblem p
     const int nkb = (kend - kbeg + BK - 1) / BK;
 
     if (nkb > 0) {
-        panel_gload<ALAY, BM, BK, EDGE>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
-        panel_gload<BLAY, BN, BK, EDGE>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
-        panel_lds_store<ALAY, BM, BK>(sA0, ra, tid);
-        panel_lds_store<BLAY, BN, BK>(sB0, rb, tid);
+        panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+        panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
+        panel_lds_store<ALAY, BM, BK, NT>(sA0, ra, tid);
+        panel_lds_store<BLAY, BN, BK, NT>(sB0, rb, tid);
     }
     __syncthreads();
 
@@ -236,8 +238,8 @@ __global__ void __launch_bounds__(256, Cfg::MINW) gemm_mfma_kernel(GemmProblem p
         const bool more = (kb + 1) < nkb;
         if (more) {  // issue next block's global loads; they land during the MFMAs
             const int k0 = kbeg + (kb + 1) * BK;
-            panel_gload<ALAY, BM, BK, EDGE>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
-            panel_gload<BLAY, BN, BK, EDGE>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+            panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
         }
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
@@ -258,8 +260,8 @@ __global__ void __launch_bounds__(256, Cfg::MINW) gemm_mfma_kernel(GemmProblem p
                                                                          acc[i][j], 0, 0, 0);
         }
         if (more) {
-            panel_lds_store<ALAY, BM, BK>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
-            panel_lds_store<BLAY, BN, BK>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
+            panel_lds_store<ALAY, BM, BK, NT>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
+            panel_lds_store<BLAY, BN, BK, NT>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
         }
         __syncthreads();
     }
@@ -301,10 +303,10 @@ inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi&
     const int grid = p.tiles_m * p.tiles_n * p.ksplits;
     if (grid <= 0) return hipSuccess;
     if (fast)
-        hipLaunchKernelGGL((gemm_mfma_kernel<Cfg, ALAY, BLAY, false, Epi>), dim3(grid), dim3(256),
+        hipLaunchKernelGGL((gemm_mfma_kernel<Cfg, ALAY, BLAY, false, Epi>), dim3(grid), dim3(Cfg::NTHREADS),
                            0, stream, p, epi);
     else
-        hipLaunchKernelGGL((gemm_mfma_kernel<Cfg, ALAY, BLAY, true, Epi>), dim3(grid), dim3(256),
+        hipLaunchKernelGGL((gemm_mfma_kernel<Cfg, ALAY, BLAY, true, Epi>), dim3(grid), dim3(Cfg::NTHREADS),
                            0, stream, p, epi);
     return hipGetLastError();
 }

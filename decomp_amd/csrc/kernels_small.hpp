@@ -27,6 +27,13 @@ __device__ __forceinline__ R wave_max(R v) {
     return v;
 }
 
+__device__ __forceinline__ void atomic_max_nonneg(float* p, float v) {
+    atomicMax(reinterpret_cast<unsigned int*>(p), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_nonneg(double* p, double v) {
+    atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
+}
+
 // Block-wide reductions for 256-thread blocks; result valid in thread 0.
 template <class R>
 __device__ __forceinline__ R block_sum_256(R v, R* sh /* >= 4 */) {
@@ -124,6 +131,25 @@ __global__ void __launch_bounds__(256) mu_quotient_kernel(const T* __restrict__ 
     }
 }
 
+// out = cur * max(sum_s slabs[s], 0) / max(den, eps): the MU quotient for a split-K numerator.
+// den: [rows, cols] (ld_den = cols) or one value per column (ld_den = 0).
+template <class T>
+__global__ void __launch_bounds__(256) mu_quotient_slabs_kernel(const T* __restrict__ cur,
+                                                                const T* __restrict__ slabs,
+                                                                long stride, int S,
+                                                                const T* __restrict__ den, long ld_den,
+                                                                long rows, long cols,
+                                                                T* __restrict__ out) {
+    const long n = rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        T nu = slabs[i];
+        for (int s = 1; s < S; ++s) nu = nu + slabs[(long)s * stride + i];
+        const long r = i / cols, c = i - r * cols;
+        const T d = den[r * ld_den + c];
+        out[i] = cur[i] * (nu > T(0) ? nu : T(0)) / (d > T(1.0e-15) ? d : T(1.0e-15));
+    }
+}
+
 // One workgroup per row of U[K, F]:  out = U / sqrt(sum |U|^2)  (strict) or
 // U / sqrt(max(sum |U|^2, 1)).  Optionally block-max of |ref - out| into rowmax[row].
 template <class T>
@@ -132,7 +158,9 @@ __global__ void __launch_bounds__(256) row_normalize_kernel(const T* __restrict_
                                                             const T* __restrict__ ref, long ld_ref,
                                                             T* __restrict__ out, long ld_out,
                                                             real_t<T>* __restrict__ rowmax,
-                                                            real_t<T>* __restrict__ norm_out = nullptr) {
+                                                            real_t<T>* __restrict__ norm_out = nullptr,
+                                                            real_t<T>* __restrict__ gmax = nullptr,
+                                                            real_t<T>* __restrict__ gmax_zero = nullptr) {
     typedef real_t<T> R;
     __shared__ R sh[4];
     __shared__ R s_inv;
@@ -164,9 +192,16 @@ __global__ void __launch_bounds__(256) row_normalize_kernel(const T* __restrict_
         }
         out[row * ld_out + j] = o;
     }
-    if (rowmax != nullptr) {
+    if (rowmax != nullptr || gmax != nullptr) {
         R m = block_max_256(md, sh);
-        if (threadIdx.x == 0) rowmax[row] = m;
+        if (threadIdx.x == 0) {
+            if (rowmax != nullptr) rowmax[row] = m;
+            // global max without a second launch: |.| >= 0, so the IEEE bit pattern is
+            // monotone in the value and a NaN (0x7fc..) wins, as np.max would have it.
+            // *gmax must be zero on entry; the other slot is cleared for the next iteration.
+            if (gmax != nullptr) atomic_max_nonneg(gmax, m);
+            if (gmax_zero != nullptr && row == 0) *gmax_zero = R(0);
+        }
     }
 }
 

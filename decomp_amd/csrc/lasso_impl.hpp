@@ -394,7 +394,7 @@ inline int gram_kk(dcp_handle* h, const T* P, const T* Q, int K, int F, LassoWs<
     GemmArgs<T> g;
     g.A = P; g.lda = F; g.B = Q; g.ldb = F; g.M = K; g.N = K; g.K = F;
     g.conjB = true;
-    plan_splits<FORM_NT>(g, kSplitTarget / 4, kMaxSplits);
+    plan_splits<FORM_NT>(g, 512, kMaxSplits);
     if ((size_t)g.ksplits * K * K > w.slab_count) return fail(h, DCP_ERR_INTERNAL, "lasso slab plan");
     DCP_LAUNCH_OK(h, (gemm<FORM_NT>(h->stream, g, EpiSlab<T>{w.slabs, K, (long)K * K})));
     hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * K)), dim3(256), 0, h->stream,

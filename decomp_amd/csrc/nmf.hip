@@ -36,8 +36,9 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     nmf_plan_stats(plan, s, masked);
     nmf_plan_update<T>(plan, F, K);
     plan.add<T>((size_t)K * W);   // stats
-    plan.add<T>((size_t)K * F);   // D_new
-    plan.add<T>(1);               // max|dD|
+    plan.add<T>((size_t)K * F);   // second D buffer
+    plan.add<T>((size_t)N * K);   // second x buffer
+    plan.add<T>(2);               // max|dD| of the two iterations in flight
     if (want_resid) {
         if (gram) plan.add<T>((size_t)N * F);
         plan.add<double>(resid_blocks);
@@ -49,20 +50,28 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     DCP_TRY(nmf_carve_stats(h, ws, s, masked));
     DCP_TRY(nmf_carve_update(h, wu, F, K));
     T* stats = ws_alloc<T>(h, (size_t)K * W);
-    T* Dnew = ws_alloc<T>(h, (size_t)K * F);
-    T* maxdiff_dev = ws_alloc<T>(h, 1);
+    T* D2 = ws_alloc<T>(h, (size_t)K * F);
+    T* X2 = ws_alloc<T>(h, (size_t)N * K);
+    T* maxdiff_dev = ws_alloc<T>(h, 2);
     T* resid_tmp = nullptr;
     double* resid_part = nullptr;
     if (want_resid) {
         resid_tmp = gram ? ws_alloc<T>(h, (size_t)N * F) : ws.f;
         resid_part = ws_alloc<double>(h, resid_blocks);
     }
-    if (!stats || !Dnew || !maxdiff_dev || (want_resid && (!resid_tmp || !resid_part)))
+    if (!stats || !D2 || !X2 || !maxdiff_dev || (want_resid && (!resid_tmp || !resid_part)))
         return fail(h, DCP_ERR_INTERNAL, "nmf workspace plan mismatch");
     void* hostv = nullptr;
-    DCP_TRY(host_scratch(h, sizeof(double) * (resid_blocks + 2), &hostv));
-    T* host_maxdiff = reinterpret_cast<T*>(hostv);
-    double* host_part = reinterpret_cast<double*>(hostv) + 1;
+    DCP_TRY(host_scratch(h, sizeof(double) * (resid_blocks + 4), &hostv));
+    T* host_md = reinterpret_cast<T*>(hostv);             // [2]
+    double* host_part = reinterpret_cast<double*>(hostv) + 2;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    DCP_HIP_OK(h, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    DCP_HIP_OK(h, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    struct EvGuard {
+        hipEvent_t* e;
+        ~EvGuard() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
+    } ev_guard{ev};
 
     const T* Ypre = Y;
     if (masked) {  // y * mask is loop invariant (grads.py:114,124 recompute it every call)
@@ -71,46 +80,72 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
         DCP_HIP_OK(h, hipGetLastError());
         Ypre = ws.Ym;
     }
+    DCP_HIP_OK(h, hipMemsetAsync(maxdiff_dev, 0, 2 * sizeof(T), h->stream));
 
-    T md = T(0);
+    // Iteration `it` reads (x_{it-1}, D_{it-1}) from (Xc, Dc) and writes (x_it, D_it) to (Xn, Dn);
+    // its max|dD| is copied to host slot it&1 behind an event.  The stop test of iteration it-1
+    // (batch_mu.py:22) is evaluated AFTER iteration it has been enqueued, so the GPU never
+    // idles on the host; when it-1 turns out to have converged, iteration it is discarded:
+    // its inputs (Xc, Dc) are exactly the state the reference returns.
+    T* Xc = X;  T* Xn = X2;
+    T* Dc = D;  T* Dn = D2;
+    int result_it = maxiter;   // batch_mu.py:26
+    T md_last = T(0);
+    bool converged = false;
     for (int it = 1; it < maxiter; ++it) {  // batch_mu.py:16
-        DCP_TRY(nmf_stats<T>(h, Ypre, mask, X, D, s, stats, ws));
-        DCP_TRY(nmf_update<T>(h, stats, D, Dnew, F, K, lik, masked, maxdiff_dev, wu));
-        DCP_HIP_OK(h, hipMemcpyAsync(host_maxdiff, maxdiff_dev, sizeof(T), hipMemcpyDeviceToHost,
-                                     h->stream));
-        if (want_resid) {
-            DCP_TRY(nmf_residual<T>(h, Y, mask, X, Dnew, N, F, K, resid_tmp, resid_part,
+        const int slot = it & 1;
+        DCP_TRY(nmf_stats<T>(h, Ypre, mask, Xc, Xn, Dc, s, stats, ws));
+        DCP_TRY(nmf_update<T>(h, stats, Dc, Dn, F, K, lik, masked, maxdiff_dev + slot, wu,
+                              maxdiff_dev + (slot ^ 1)));
+        DCP_HIP_OK(h, hipMemcpyAsync(host_md + slot, maxdiff_dev + slot, sizeof(T),
+                                     hipMemcpyDeviceToHost, h->stream));
+        DCP_HIP_OK(h, hipEventRecord(ev[slot], h->stream));
+        if (want_resid) {   // parity/debug mode: synchronous
+            DCP_TRY(nmf_residual<T>(h, Y, mask, Xn, Dn, N, F, K, resid_tmp, resid_part,
                                     resid_blocks));
             DCP_HIP_OK(h, hipMemcpyAsync(host_part, resid_part, sizeof(double) * resid_blocks,
                                          hipMemcpyDeviceToHost, h->stream));
-        }
-        // D <- D_new either way (on convergence the reference returns D_new, batch_mu.py:23)
-        DCP_HIP_OK(h, hipMemcpyAsync(D, Dnew, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice,
-                                     h->stream));
-        DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
-        md = *host_maxdiff;
-        if (want_resid) {
+            DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
             double acc = 0.0;
             for (int i = 0; i < resid_blocks; ++i) acc += host_part[i];
             resid_trace[it - 1] = (T)sqrt(acc);
         }
-        if (md < tol) {  // batch_mu.py:22 (a NaN compares false, as in NumPy)
-            *it_out = it;
-            if (last_maxdiff) *last_maxdiff = md;
-            return DCP_OK;
+        if (it > 1) {   // stop test of the PREVIOUS iteration
+            DCP_HIP_OK(h, hipEventSynchronize(ev[slot ^ 1]));
+            md_last = host_md[slot ^ 1];
+            if (md_last < tol) {   // a NaN compares false, as in NumPy
+                result_it = it - 1;
+                converged = true;
+                break;             // (Xc, Dc) hold x_{it-1} and D_new of iteration it-1
+            }
         }
+        T* t = Xc; Xc = Xn; Xn = t;
+        t = Dc; Dc = Dn; Dn = t;
     }
-    *it_out = maxiter;  // batch_mu.py:26
-    if (last_maxdiff) *last_maxdiff = md;
+    if (!converged && maxiter > 1) {   // stop test of the last iteration
+        const int slot = (maxiter - 1) & 1;
+        DCP_HIP_OK(h, hipEventSynchronize(ev[slot]));
+        md_last = host_md[slot];
+        if (md_last < tol) result_it = maxiter - 1;
+    }
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));   // drain (incl. a discarded iteration)
+    if (Xc != X)
+        DCP_HIP_OK(h, hipMemcpyAsync(X, Xc, sizeof(T) * (size_t)N * K, hipMemcpyDeviceToDevice,
+                                     h->stream));
+    if (Dc != D)
+        DCP_HIP_OK(h, hipMemcpyAsync(D, Dc, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice,
+                                     h->stream));
     DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    *it_out = result_it;
+    if (last_maxdiff) *last_maxdiff = md_last;
     return DCP_OK;
 }
 
 template <class T>
-int nmf_mu_stats_api(dcp_handle* h, const T* Y, const T* mask, T* X, const T* D, int64_t N,
-                     int64_t F, int64_t K, int lik, T* stats) {
+int nmf_mu_stats_api(dcp_handle* h, const T* Y, const T* mask, const T* X, T* X_out, const T* D,
+                     int64_t N, int64_t F, int64_t K, int lik, T* stats) {
     DCP_TRY(check_nmf_args(h, Y, X, D, N, F, K, lik));
-    if (!stats) return fail(h, DCP_ERR_INVALID, "stats is null");
+    if (!stats || !X_out) return fail(h, DCP_ERR_INVALID, "stats / X_out is null");
     DCP_HIP_OK(h, hipSetDevice(h->device));
     const bool masked = mask != nullptr;
     NmfShape<T> s{N, F, K, lik, masked};
@@ -127,12 +162,12 @@ int nmf_mu_stats_api(dcp_handle* h, const T* Y, const T* mask, T* X, const T* D,
         DCP_HIP_OK(h, hipGetLastError());
         Ypre = ws.Ym;
     }
-    return nmf_stats<T>(h, Ypre, mask, X, D, s, stats, ws);
+    return nmf_stats<T>(h, Ypre, mask, X, X_out, D, s, stats, ws);
 }
 
 template <class T>
 int nmf_mu_update_api(dcp_handle* h, const T* stats, const T* D, T* D_new, int64_t F, int64_t K,
-                      int lik, int masked, T* maxdiff_dev) {
+                      int lik, int masked, T* maxdiff_dev, T* maxdiff_next) {
     if (!h) return DCP_ERR_INVALID;
     if (!stats || !D || !D_new || !maxdiff_dev) return fail(h, DCP_ERR_INVALID, "null pointer");
     if (F <= 0 || K <= 0) return fail(h, DCP_ERR_INVALID, "sizes must be positive");
@@ -145,7 +180,7 @@ int nmf_mu_update_api(dcp_handle* h, const T* stats, const T* D, T* D_new, int64
     ws_reset(h);
     NmfUpdateWs<T> wu;
     DCP_TRY(nmf_carve_update(h, wu, F, K));
-    return nmf_update<T>(h, stats, D, D_new, F, K, lik, masked != 0, maxdiff_dev, wu);
+    return nmf_update<T>(h, stats, D, D_new, F, K, lik, masked != 0, maxdiff_dev, wu, maxdiff_next);
 }
 
 template <class T>
@@ -195,22 +230,27 @@ int dcp_nmf_mu_f64(dcp_handle* h, const double* Y, const double* mask, double* X
     return nmf_mu_solve<double>(h, Y, mask, X, D, N, F, K, likelihood, tol, maxiter, it_out,
                                 last_maxdiff, resid_trace);
 }
-int dcp_nmf_mu_stats_f32(dcp_handle* h, const float* Y, const float* mask, float* X, const float* D,
-                         int64_t N, int64_t F, int64_t K, int likelihood, float* stats) {
-    return nmf_mu_stats_api<float>(h, Y, mask, X, D, N, F, K, likelihood, stats);
+int dcp_nmf_mu_stats_f32(dcp_handle* h, const float* Y, const float* mask, const float* X,
+                         float* X_out, const float* D, int64_t N, int64_t F, int64_t K,
+                         int likelihood, float* stats) {
+    return nmf_mu_stats_api<float>(h, Y, mask, X, X_out, D, N, F, K, likelihood, stats);
 }
-int dcp_nmf_mu_stats_f64(dcp_handle* h, const double* Y, const double* mask, double* X,
-                         const double* D, int64_t N, int64_t F, int64_t K, int likelihood,
-                         double* stats) {
-    return nmf_mu_stats_api<double>(h, Y, mask, X, D, N, F, K, likelihood, stats);
+int dcp_nmf_mu_stats_f64(dcp_handle* h, const double* Y, const double* mask, const double* X,
+                         double* X_out, const double* D, int64_t N, int64_t F, int64_t K,
+                         int likelihood, double* stats) {
+    return nmf_mu_stats_api<double>(h, Y, mask, X, X_out, D, N, F, K, likelihood, stats);
 }
 int dcp_nmf_mu_update_f32(dcp_handle* h, const float* stats, const float* D, float* D_new,
-                          int64_t F, int64_t K, int likelihood, int masked, float* maxdiff_dev) {
-    return nmf_mu_update_api<float>(h, stats, D, D_new, F, K, likelihood, masked, maxdiff_dev);
+                          int64_t F, int64_t K, int likelihood, int masked, float* maxdiff_dev,
+                          float* maxdiff_next) {
+    return nmf_mu_update_api<float>(h, stats, D, D_new, F, K, likelihood, masked, maxdiff_dev,
+                                    maxdiff_next);
 }
 int dcp_nmf_mu_update_f64(dcp_handle* h, const double* stats, const double* D, double* D_new,
-                          int64_t F, int64_t K, int likelihood, int masked, double* maxdiff_dev) {
-    return nmf_mu_update_api<double>(h, stats, D, D_new, F, K, likelihood, masked, maxdiff_dev);
+                          int64_t F, int64_t K, int likelihood, int masked, double* maxdiff_dev,
+                          double* maxdiff_next) {
+    return nmf_mu_update_api<double>(h, stats, D, D_new, F, K, likelihood, masked, maxdiff_dev,
+                                     maxdiff_next);
 }
 int dcp_nmf_residual_f32(dcp_handle* h, const float* Y, const float* mask, const float* X,
                          const float* D, int64_t N, int64_t F, int64_t K, double* out) {

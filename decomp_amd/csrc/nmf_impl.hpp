@@ -26,8 +26,9 @@ inline int64_t nmf_stats_width(int64_t F, int64_t K, int likelihood, bool masked
     return (likelihood == DCP_LIK_L2 && !masked) ? (F + K) : 2 * F;
 }
 
-// Number of resident workgroup slots we size split-K grids for (4 WG/CU x 256 CUs).
-constexpr int kSplitTarget = 2048;
+// Workgroups a split-K grid is sized for: ONE round of resident 128x128 workgroups
+// (4 per CU x 256 CUs).  Measured: x^T Y at 16 splits (1024 WGs) 1.05 ms, at 30 (2 rounds) 1.15.
+constexpr int kSplitTarget = 1024;
 constexpr int kMaxSplits = 64;
 
 template <class T>
@@ -50,6 +51,24 @@ struct NmfStatsWs {
     size_t slab_count = 0;
 };
 
+// Split-K plan of the x-update GEMM (Y D^T, [N,F]x[K,F]): only when the row tiles alone
+// cannot fill the chip (rows per GPU small, e.g. one shard of an 8-GPU run).
+template <class T>
+inline int nmf_xupdate_splits(int64_t N, int64_t F, int64_t K, GemmArgs<T>& pg) {
+    pg.M = (int)N; pg.N = (int)K; pg.K = (int)F;
+    pg.tile = TILE_AUTO;
+    int bm = 64, bn = 64;
+    if (std::is_same<T, float>::value) tier_dims(pick_tier<FORM_NT>(pg.M, pg.N, pg.K, TILE_AUTO), bm, bn);
+    const long tiles = (long)ceil_div(N, bm) * ceil_div(K, bn);
+    const long enough = (bm == 256) ? 192 : 512;
+    if (tiles >= enough || F < 1024) {
+        pg.ksplits = 1;
+        return 1;
+    }
+    plan_splits<FORM_NT>(pg, (bm == 256) ? 256 : 1024, 8);
+    return pg.ksplits;
+}
+
 template <class T>
 inline size_t nmf_slab_elems(const NmfShape<T>& s) {
     // the largest split-K product of the step: stats GEMM [K, W] (and G [K,K])
@@ -60,9 +79,13 @@ inline size_t nmf_slab_elems(const NmfShape<T>& s) {
     size_t stats_slabs = (size_t)a.ksplits * s.K * W;
     GemmArgs<T> g;
     g.M = (int)s.K; g.N = (int)s.K; g.K = (int)s.F;
-    plan_splits<FORM_NT>(g, kSplitTarget / 4, kMaxSplits);
+    plan_splits<FORM_NT>(g, 512, kMaxSplits);
     size_t g_slabs = (size_t)g.ksplits * s.K * s.K;
-    return stats_slabs > g_slabs ? stats_slabs : g_slabs;
+    GemmArgs<T> pg;
+    const int ps = nmf_xupdate_splits<T>(s.N, s.F, s.K, pg);
+    size_t x_slabs = ps > 1 ? (size_t)ps * s.N * s.K : 0;
+    size_t m = stats_slabs > g_slabs ? stats_slabs : g_slabs;
+    return m > x_slabs ? m : x_slabs;
 }
 
 template <class T>
@@ -138,7 +161,7 @@ inline int column_sums(dcp_handle* h, const T* a, long ld, long rows, long cols,
 // ---- x update + local statistics ------------------------------------------------------
 // Ypre: Y already multiplied by the mask (or Y itself when there is no mask).
 template <class T>
-inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, T* X, const T* D,
+inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, T* Xout, const T* D,
                      const NmfShape<T>& s, T* stats, NmfStatsWs<T>& w) {
     hipStream_t st = h->stream;
     const int N = (int)s.N, F = (int)s.F, K = (int)s.K;
@@ -146,7 +169,7 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, T* X, const T*
     const int W = (int)nmf_stats_width(s.F, s.K, s.lik, s.masked);
 
     // forward product x.D with an elementwise epilogue into the [N,F] intermediate w.f
-    auto forward = [&]() -> int {
+    auto forward = [&](const T* X) -> int {
         ProfScope ps(h, DCP_PROF_FWD);
         GemmArgs<T> fa;
         fa.A = X; fa.lda = K; fa.B = D; fa.ldb = F; fa.M = N; fa.N = F; fa.K = K;
@@ -166,7 +189,7 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, T* X, const T*
             ProfScope ps(h, DCP_PROF_GRAM);
             GemmArgs<T> g;
             g.A = D; g.lda = F; g.B = D; g.ldb = F; g.M = K; g.N = K; g.K = F;
-            plan_splits<FORM_NT>(g, kSplitTarget / 4, kMaxSplits);
+            plan_splits<FORM_NT>(g, 512, kMaxSplits);
             DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, g, EpiSlab<T>{w.slabs, K, (long)K * K})));
             hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * K)), dim3(256), 0,
                                st, w.slabs, (long)K * K, g.ksplits, (long)K * K, w.G);
@@ -175,17 +198,17 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, T* X, const T*
         {   // Q = x G
             ProfScope ps(h, DCP_PROF_XNEG);
             GemmArgs<T> q;
-            q.A = X; q.lda = K; q.B = w.G; q.ldb = K; q.M = N; q.N = K; q.K = K;
+            q.A = Xin; q.lda = K; q.B = w.G; q.ldb = K; q.M = N; q.N = K; q.K = K;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, q, EpiStore<T>{w.Q, K})));
         }
     } else if (s.lik == DCP_LIK_L2) {
-        DCP_TRY(forward());
+        DCP_TRY(forward(Xin));
         ProfScope ps(h, DCP_PROF_XNEG);   // Q = f D^T
         GemmArgs<T> q;
         q.A = w.f; q.lda = F; q.B = D; q.ldb = F; q.M = N; q.N = K; q.K = F;
         DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, q, EpiStore<T>{w.Q, K})));
     } else {
-        DCP_TRY(forward());
+        DCP_TRY(forward(Xin));
         xnum_A = w.f;
         ProfScope ps(h, DCP_PROF_XNEG);
         if (!s.masked) {   // neg = colsum(D), one value per column of x (grads.py:146)
@@ -200,12 +223,28 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, T* X, const T*
             DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, q, EpiStore<T>{w.Q, K})));
         }
     }
-    {   // x <- x * max(pos, 0) / max(neg, eps): quotient fused into the GEMM epilogue
+    {   // x <- x * max(pos, 0) / max(neg, eps)
         ProfScope ps(h, DCP_PROF_XUPDATE);
         GemmArgs<T> pg;
         pg.A = xnum_A; pg.lda = F; pg.B = D; pg.ldb = F; pg.M = N; pg.N = K; pg.K = F;
-        DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, pg, EpiMuNum<T>{X, K, xden, ld_xden, X, K})));
+        const int psplits = nmf_xupdate_splits<T>(s.N, s.F, s.K, pg);
+        if (psplits <= 1) {
+            // enough row tiles to fill the chip: quotient fused into the GEMM epilogue
+            pg.ksplits = 1;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, pg, EpiMuNum<T>{Xin, K, xden, ld_xden, Xout, K})));
+        } else {
+            // few rows per GPU (a shard of a multi-GPU run): split the F reduction so that all
+            // CUs work, then sum the slabs in order inside the quotient kernel
+            if ((size_t)pg.ksplits * N * K > w.slab_count)
+                return fail(h, DCP_ERR_INTERNAL, "nmf x-update slab plan mismatch");
+            DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, pg, EpiSlab<T>{w.slabs, K, (long)N * K})));
+            hipLaunchKernelGGL((mu_quotient_slabs_kernel<T>), dim3(grid_for((long)N * K)), dim3(256),
+                               0, st, Xin, (const T*)w.slabs, (long)N * K, pg.ksplits, xden,
+                               (long)ld_xden, (long)N, (long)K, Xout);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+        }
     }
+    const T* X = Xout;
 
     // ---------------- local D-side sums with the NEW x ----------------
     GemmArgs<T> sa;
@@ -213,10 +252,10 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, T* X, const T*
     if (gram) {
         sa.B = Ypre; sa.ldb = F; sa.B2 = X; sa.ldb2 = K; sa.n_b1 = F;      // [ x^T Y | x^T x ]
     } else if (s.lik == DCP_LIK_L2) {
-        DCP_TRY(forward());
+        DCP_TRY(forward(X));
         sa.B = Ypre; sa.ldb = F; sa.B2 = w.f; sa.ldb2 = F; sa.n_b1 = F;    // [ x^T Ym | x^T f ]
     } else {
-        DCP_TRY(forward());
+        DCP_TRY(forward(X));
         if (s.masked) {
             sa.B = w.f; sa.ldb = F; sa.B2 = mask; sa.ldb2 = F; sa.n_b1 = F;  // [ x^T r | x^T M ]
         } else {
@@ -253,7 +292,8 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, T* X, const T*
 // ---- D update from the (all-reduced) statistics ---------------------------------------
 template <class T>
 inline int nmf_update(dcp_handle* h, const T* stats, const T* D, T* D_new, int64_t F64, int64_t K64,
-                      int lik, bool masked, T* maxdiff_dev, NmfUpdateWs<T>& w) {
+                      int lik, bool masked, T* maxdiff_dev, NmfUpdateWs<T>& w,
+                      T* maxdiff_next = nullptr) {
     hipStream_t st = h->stream;
     const int F = (int)F64, K = (int)K64;
     const bool gram = (lik == DCP_LIK_L2 && !masked);
@@ -275,8 +315,18 @@ inline int nmf_update(dcp_handle* h, const T* stats, const T* D, T* D_new, int64
     }
     // D_new = l2_strict(U) ; max |D - D_new|
     ProfScope ps(h, DCP_PROF_DNORM);
+    if (maxdiff_next != nullptr) {
+        // ping-pong slots: *maxdiff_dev is zero on entry (cleared by the previous iteration),
+        // the max is formed with one atomic per row, and the other slot is cleared for the next
+        hipLaunchKernelGGL((row_normalize_kernel<T>), dim3(K), dim3(256), 0, st, w.U, (long)F,
+                           (long)F, 1, D, (long)F, D_new, (long)F, (T*)nullptr, (T*)nullptr,
+                           maxdiff_dev, maxdiff_next);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        return DCP_OK;
+    }
     hipLaunchKernelGGL((row_normalize_kernel<T>), dim3(K), dim3(256), 0, st, w.U, (long)F, (long)F,
-                       1, D, (long)F, D_new, (long)F, w.rowmax);
+                       1, D, (long)F, D_new, (long)F, w.rowmax, (T*)nullptr, (T*)nullptr,
+                       (T*)nullptr);
     DCP_LAUNCH_OK(h, hipGetLastError());
     hipLaunchKernelGGL((final_max_kernel<T>), dim3(1), dim3(256), 0, st, w.rowmax, (long)K,
                        maxdiff_dev);

@@ -54,23 +54,43 @@ int count_negative_api(dcp_handle* h, const T* x, int64_t n, int64_t* count) {
     return DCP_OK;
 }
 
-// extra ("wide") tile shapes, reachable through the test hook for tuning sweeps
-typedef TileCfg<128, 256, 16, 64, 128, 2> CfgWideNT;
-typedef TileCfg<256, 128, 16, 128, 64, 2> CfgWideTN;
+// extra tile shapes, reachable through the test hook for tuning sweeps (tile codes 3..9)
+typedef TileCfg<128, 256, 16, 64, 128, 2> CfgWideNT;     // 3 (NT, NN)
+typedef TileCfg<256, 128, 16, 128, 64, 2> CfgWideTN;     // 3 (TN)
+typedef TileCfg<128, 128, 32, 64, 64, 2> CfgDeep;        // 4: BK = 32
+typedef TileCfg<128, 128, 16, 64, 32, 2> Cfg8w;          // 5: 8 waves, 64x32 per wave
+typedef TileCfg<256, 128, 16, 64, 64, 2> Cfg8wBig;       // 6: 8 waves, 256x128
+typedef TileCfg<256, 256, 16, 64, 64, 1> Cfg16w;         // 7: 16 waves, 256x256
+typedef TileCfg<128, 128, 16, 32, 64, 2> Cfg8wT;         // 8: 8 waves, 32x64 per wave
+typedef TileCfg<256, 128, 32, 64, 64, 1> Cfg8wBigDeep;   // 9: 8 waves, 256x128, BK = 32
+
+template <class Cfg, int FORM, class Epi>
+hipError_t hook_cfg(hipStream_t st, const GemmArgs<float>& a, const Epi& epi) {
+    GemmProblem p;
+    p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb;
+    p.B2 = nullptr; p.ldb2 = 0; p.n_b1 = a.N;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.ksplits = a.ksplits; p.klen = a.klen;
+    p.tiles_m = p.tiles_n = 0;
+    p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
+    constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
+    constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
+    return launch_gemm_mfma<Cfg, AL, BL, Epi>(st, p, epi);
+}
 
 template <int FORM, class T, class Epi>
 hipError_t gemm_hook_launch(hipStream_t st, const GemmArgs<T>& a, int tile, const Epi& epi) {
     if constexpr (std::is_same<T, float>::value) {
-        if (tile == 3) {
-            GemmProblem p;
-            p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb;
-            p.B2 = nullptr; p.ldb2 = 0; p.n_b1 = a.N;
-            p.M = a.M; p.N = a.N; p.K = a.K; p.ksplits = a.ksplits; p.klen = a.klen;
-            p.tiles_m = p.tiles_n = 0;
-            p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
-            if (FORM == FORM_NT) return launch_gemm_mfma<CfgWideNT, KMAJOR, KMAJOR, Epi>(st, p, epi);
-            if (FORM == FORM_NN) return launch_gemm_mfma<CfgWideNT, KMAJOR, XMAJOR, Epi>(st, p, epi);
-            return launch_gemm_mfma<CfgWideTN, XMAJOR, XMAJOR, Epi>(st, p, epi);
+        switch (tile) {
+            case 3:
+                if (FORM == FORM_TN) return hook_cfg<CfgWideTN, FORM>(st, a, epi);
+                return hook_cfg<CfgWideNT, FORM>(st, a, epi);
+            case 4: return hook_cfg<CfgDeep, FORM>(st, a, epi);
+            case 5: return hook_cfg<Cfg8w, FORM>(st, a, epi);
+            case 6: return hook_cfg<Cfg8wBig, FORM>(st, a, epi);
+            case 7: return hook_cfg<Cfg16w, FORM>(st, a, epi);
+            case 8: return hook_cfg<Cfg8wT, FORM>(st, a, epi);
+            case 9: return hook_cfg<Cfg8wBigDeep, FORM>(st, a, epi);
+            default: break;
         }
     }
     return gemm<FORM>(st, a, epi);
@@ -88,7 +108,7 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
     a.A = A; a.B = B; a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = (form == FORM_TN) ? M : K;
     a.ldb = (form == FORM_NT) ? K : N;
-    a.tile = (tile == 3) ? TILE_LARGE : tile;
+    a.tile = (tile >= 3) ? TILE_LARGE : tile;   // hook-only shapes plan splits as 128x128
     hipError_t e = hipSuccess;
     if (ksplits > 1) {
         const long kblocks = (K + 15) / 16;

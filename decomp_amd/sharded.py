@@ -16,12 +16,18 @@ from . import _arrays, _hip
 
 
 class HipStepBackend(object):
-    """The two halves of one MU iteration on this rank's GPU, through the C ABI."""
+    """The two halves of one MU iteration on this rank's GPU, through the C ABI.
+
+    x is double buffered: ``local_stats`` reads the current x and writes the next one, so
+    the iteration that was enqueued speculatively (see ``mu_loop``) can be discarded with
+    ``rollback``.  ``x`` is always the buffer holding the current iterate."""
 
     def __init__(self, y, mask, x, D, lik):
         import torch
         self.torch = torch
-        self.y, self.mask, self.x, self.lik = y, mask, x, lik
+        self.y, self.mask, self.lik = y, mask, lik
+        self.x = x
+        self._x_other = torch.empty_like(x)
         self.N, self.F = y.shape
         self.K = D.shape[0]
         self.sfx = _arrays.suffix(D)
@@ -36,18 +42,24 @@ class HipStepBackend(object):
         lib, h = _arrays.lib_handle(D)
         fn = getattr(lib, 'dcp_nmf_mu_stats_' + self.sfx)
         _hip.check(h, fn(h, _arrays.ptr(self.y), _arrays.ptr(self.mask), _arrays.ptr(self.x),
-                         _arrays.ptr(D), self.N, self.F, self.K, self.lik,
-                         _arrays.ptr(self.stats)), 'dcp_nmf_mu_stats')
+                         _arrays.ptr(self._x_other), _arrays.ptr(D), self.N, self.F, self.K,
+                         self.lik, _arrays.ptr(self.stats)), 'dcp_nmf_mu_stats')
+        self.x, self._x_other = self._x_other, self.x
         return self.stats
+
+    def rollback(self):
+        """Forget the last local_stats: x is again the iterate it started from."""
+        self.x, self._x_other = self._x_other, self.x
 
     def update(self, stats, D, D_new, slot):
         """Enqueue the D update; its max|dD| lands asynchronously in host slot ``slot``."""
         lib, h = _arrays.lib_handle(D)
         fn = getattr(lib, 'dcp_nmf_mu_update_' + self.sfx)
-        md = self.maxdiff[slot:slot + 1]
+        md = self.maxdiff[slot:slot + 1]            # zero on entry (ping-pong, see the C ABI)
+        nxt = self.maxdiff[(slot ^ 1):(slot ^ 1) + 1]
         _hip.check(h, fn(h, _arrays.ptr(stats), _arrays.ptr(D), _arrays.ptr(D_new), self.F,
-                         self.K, self.lik, 0 if self.mask is None else 1, _arrays.ptr(md)),
-                   'dcp_nmf_mu_update')
+                         self.K, self.lik, 0 if self.mask is None else 1, _arrays.ptr(md),
+                         _arrays.ptr(nxt)), 'dcp_nmf_mu_update')
         self._host[slot:slot + 1].copy_(md, non_blocking=True)
         ev = self.torch.cuda.Event()
         ev.record()
@@ -57,22 +69,19 @@ class HipStepBackend(object):
         self._events[slot].synchronize()
         return float(self._host[slot])
 
-    def snapshot_x(self):
-        return self.x.clone()
-
-    def restore_x(self, snap):
-        self.x.copy_(snap)
-
 
 def mu_loop(backend, D, tol, maxiter, group=None, world_size=1, new_like=None):
     """batch_mu.py:16-26 with the statistics all-reduced over ``group``.
 
-    backend: object with local_stats(D) -> stats array, update(stats, D, D_new, slot),
-             read_maxdiff(slot) -> float  (HipStepBackend; the CPU tests of the host logic
-             inject an oracle-backed stand-in).
-    Returns (it, D).  backend.x is updated in place.  The host reads max|dD| of
-    iteration i right after enqueueing it (one small device->host copy per iteration, as
-    the reference's `if xp.max(...) < tol` does).
+    backend: local_stats(D) -> stats array (advances backend.x), rollback(),
+             update(stats, D, D_new, slot), read_maxdiff(slot) -> float
+             (HipStepBackend; the CPU tests of this host logic inject an oracle-backed
+             stand-in).
+    Returns (it, D); backend.x is the matching x.  The stop test of iteration i
+    (batch_mu.py:22) is read AFTER iteration i+1 has been enqueued, so neither the GPU
+    nor the collective ever waits for the host; if iteration i did converge, the
+    speculative iteration i+1 is rolled back.  Every rank sees the same all-reduced
+    statistics, hence takes the same decision at the same iteration.
     """
     import torch.distributed as dist
     D_new = new_like(D)
@@ -81,9 +90,12 @@ def mu_loop(backend, D, tol, maxiter, group=None, world_size=1, new_like=None):
         if world_size > 1:
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         backend.update(stats, D, D_new, it & 1)
-        if backend.read_maxdiff(it & 1) < tol:
-            return it, D_new
+        if it > 1 and backend.read_maxdiff((it - 1) & 1) < tol:
+            backend.rollback()              # discard iteration `it`
+            return it - 1, D                # D is D_new of iteration it-1
         D, D_new = D_new, D
+    if maxiter > 1 and backend.read_maxdiff((maxiter - 1) & 1) < tol:
+        return maxiter - 1, D
     return maxiter, D
 
 
@@ -120,4 +132,4 @@ def nmf_solve_sharded(y_local, D, x_local=None, tol=1.0e-3, maxiter=1000, likeli
     backend = HipStepBackend(y, m, x, Dd, lik)
     it, Dout = mu_loop(backend, Dd, tol, maxiter, group=group, world_size=world,
                        new_like=torch.empty_like)
-    return it, Dout, x
+    return it, Dout, backend.x

@@ -114,28 +114,33 @@ int dcp_nmf_mu_f64(dcp_handle* h, const double* Y, const double* mask, double* X
                    int* it_out, double* last_maxdiff, double* resid_trace);
 
 /* One iteration split at the data-parallel exchange point, asynchronous:
- *   dcp_nmf_mu_stats_*  : x <- update_x (grads.py:77-84), then this rank's share of
- *                         the D-side sums (grads.py:117-125) into stats:
+ *   dcp_nmf_mu_stats_*  : X_out <- update_x(X) (grads.py:77-84; X_out may alias X, or be a
+ *                         second buffer so that the caller can overlap the stop test of the
+ *                         previous iteration), then this rank's share of the D-side sums
+ *                         (grads.py:117-125, with the NEW x) into stats:
  *                           l2, no mask : stats[K, F+K] = [ x^T Y | x^T x ]
  *                           otherwise   : stats[K, 2F]  = [ numerator | denominator ]
  *                         (the caller all-reduces stats over ranks: sums over rows)
  *   dcp_nmf_mu_update_* : D_new <- l2_strict(D o max(num,0) / max(den,1e-15))
  *                         (grads.py:86-93, batch_mu.py:21) written to D_new, and
  *                         max|D - D_new| written to the DEVICE scalar maxdiff_dev.
+ *                         maxdiff_next (nullable): when given, *maxdiff_dev must be 0 on
+ *                         entry, the max is formed by one atomic per row (no extra launch)
+ *                         and *maxdiff_next is cleared for the following iteration.
  * stats width: dcp_nmf_mu_stats_width(). */
 int64_t dcp_nmf_mu_stats_width(int64_t F, int64_t K, int likelihood, int masked);
-int dcp_nmf_mu_stats_f32(dcp_handle* h, const float* Y, const float* mask, float* X,
-                         const float* D, int64_t N, int64_t F, int64_t K, int likelihood,
-                         float* stats);
-int dcp_nmf_mu_stats_f64(dcp_handle* h, const double* Y, const double* mask, double* X,
-                         const double* D, int64_t N, int64_t F, int64_t K, int likelihood,
-                         double* stats);
+int dcp_nmf_mu_stats_f32(dcp_handle* h, const float* Y, const float* mask, const float* X,
+                         float* X_out, const float* D, int64_t N, int64_t F, int64_t K,
+                         int likelihood, float* stats);
+int dcp_nmf_mu_stats_f64(dcp_handle* h, const double* Y, const double* mask, const double* X,
+                         double* X_out, const double* D, int64_t N, int64_t F, int64_t K,
+                         int likelihood, double* stats);
 int dcp_nmf_mu_update_f32(dcp_handle* h, const float* stats, const float* D, float* D_new,
                           int64_t F, int64_t K, int likelihood, int masked,
-                          float* maxdiff_dev);
+                          float* maxdiff_dev, float* maxdiff_next);
 int dcp_nmf_mu_update_f64(dcp_handle* h, const double* stats, const double* D, double* D_new,
                           int64_t F, int64_t K, int likelihood, int masked,
-                          double* maxdiff_dev);
+                          double* maxdiff_dev, double* maxdiff_next);
 
 /* ||(Y - X D) o mask||_F (parity metric of SURVEY 8d; mask nullable). */
 int dcp_nmf_residual_f32(dcp_handle* h, const float* Y, const float* mask, const float* X,

@@ -26,13 +26,17 @@ class OracleStepBackend(object):
 
     def local_stats(self, D):
         Dn = D.numpy()
-        self.x[...] = self.o.update_x(self.y, self.x, Dn, self.mask, self.lik)
+        self._x_prev = self.x
+        self.x = self.o.update_x(self.y, self.x, Dn, self.mask, self.lik)
         pos, neg = self.o._parts_d(self.y, self.x, Dn, self.mask, self.lik)
         if self.lik == 'l2' and self.mask is None:
             stats = np.concatenate([self.x.T @ self.y, self.x.T @ self.x], axis=1)
         else:
             stats = np.concatenate([pos, np.broadcast_to(neg, pos.shape)], axis=1)
         return torch.from_numpy(np.ascontiguousarray(stats))
+
+    def rollback(self):
+        self.x = self._x_prev
 
     def update(self, stats, D, D_new, slot):
         from oracle.common import l2_strict
@@ -75,7 +79,7 @@ def _worker(rank, world, port, lik, masked, tol, maxiter, q):
         D = torch.from_numpy(l2_strict(D0))
         it, Dout = sharded.mu_loop(be, D, tol, maxiter, world_size=world,
                                    new_like=torch.empty_like)
-        q.put((rank, it, Dout.numpy().copy(), x.copy()))
+        q.put((rank, it, Dout.numpy().copy(), be.x.copy()))
     finally:
         dist.destroy_process_group()
 

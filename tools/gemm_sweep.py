@@ -50,32 +50,30 @@ def main():
     ap.add_argument('--f', type=int, default=4096)
     ap.add_argument('--k', type=int, default=256)
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--tiles', default='1,3,4,5,6,7,8,9')
     a = ap.parse_args()
     N, F, K = a.n, a.f, a.k
     rows = []
+    tiles = [int(t) for t in a.tiles.split(',')]
     # P = Y D^T : NT [N,F]x[K,F]
-    for tile in (1, 3, 2):
+    for tile in tiles:
         ms = time_gemm(0, N, K, F, 1, tile, a.reps)
         rows.append(('NT Y.D^T', tile, 1, ms, 2.0 * N * K * F / ms / 1e9))
     # stats = x^T [Y] : TN, split-K
-    for tile in (1, 3):
-        for ks in (8, 15, 16, 30, 32, 45, 60, 64):
+    for tile in tiles:
+        for ks in (16, 30):
             ms = time_gemm(2, K, F, N, ks, tile, a.reps)
             rows.append(('TN x^T.Y', tile, ks, ms, 2.0 * N * K * F / ms / 1e9))
     # Q = x G : NN [N,K]x[K,K]
-    for tile in (1, 3, 2):
+    for tile in tiles:
         ms = time_gemm(1, N, K, K, 1, tile, a.reps)
         rows.append(('NN x.G', tile, 1, ms, 2.0 * N * K * K / ms / 1e9))
     # f = x D : NN [N,K]x[K,F] (masked path)
-    for tile in (1, 3):
+    for tile in tiles:
         ms = time_gemm(1, N, F, K, 1, tile, a.reps)
         rows.append(('NN x.D', tile, 1, ms, 2.0 * N * K * F / ms / 1e9))
-    # G = D D^T : NT small, split
-    for ks in (8, 16, 32, 64):
-        ms = time_gemm(0, K, K, F, ks, 2, a.reps)
-        rows.append(('NT D.D^T', 2, ks, ms, 2.0 * K * K * F / ms / 1e9))
     # square reference point
-    for tile in (1, 3):
+    for tile in tiles:
         ms = time_gemm(0, 4096, 4096, 4096, 1, tile, a.reps)
         rows.append(('NT 4096^3', tile, 1, ms, 2.0 * 4096 ** 3 / ms / 1e9))
     print('%-12s %4s %6s %10s %10s' % ('gemm', 'tile', 'splits', 'ms', 'TFLOP/s'))
