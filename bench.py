@@ -103,6 +103,8 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-sharded', action='store_true',
+                    help='(analysis only) use the multi-GPU Python step loop even at N = 1')
     ap.add_argument('--rows', type=int, default=0,
                     help='(analysis only) rows of Y on this GPU instead of 65536/N: time one '
                          'shard of a larger run without the collective')
@@ -146,7 +148,7 @@ def main():
 
     def run(n_steps):
         """n_steps MU iterations (tol = 0: the stop test is evaluated, never met)."""
-        if world == 1:
+        if world == 1 and not args.force_sharded:
             it = ctypes.c_int(0)
             rc = lib.dcp_nmf_mu_f32(h, _arrays.ptr(Y), None, _arrays.ptr(x), _arrays.ptr(D),
                                     rows, N_FEAT, N_ATOMS, _hip.LIK_L2, ctypes.c_float(0.0),

@@ -169,7 +169,13 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     typedef PanelGeom<ALAY, BM, BK, NT> GA;
     typedef PanelGeom<BLAY, BN, BK, NT> GB;
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * (GA::ELEMS + GB::ELEMS)];
+    // Tiles whose double-buffered panels exceed the 64 KiB static limit use dynamic LDS
+    // (the launcher raises the function's dynamic-LDS cap once).
+    constexpr int LDS_FLOATS = 2 * (GA::ELEMS + GB::ELEMS);
+    constexpr bool DYN = (LDS_FLOATS * 4 > 65536);
+    __shared__ __attribute__((aligned(16))) float smem_static[DYN ? 4 : LDS_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    float* smem = DYN ? smem_dyn : smem_static;
     float* sA0 = smem;
     float* sB0 = smem + 2 * GA::ELEMS;
 
@@ -302,12 +308,26 @@ inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi&
     if (p.B2 != nullptr) fast = fast && (p.n_b1 % BN == 0) && (p.ldb2 % 4 == 0) && al16(p.B2);
     const int grid = p.tiles_m * p.tiles_n * p.ksplits;
     if (grid <= 0) return hipSuccess;
+    constexpr int lds_bytes = 8 * (PanelGeom<ALAY, BM, BK, Cfg::NTHREADS>::ELEMS +
+                                   PanelGeom<BLAY, BN, BK, Cfg::NTHREADS>::ELEMS);
+    constexpr int dyn_bytes = lds_bytes > 65536 ? lds_bytes : 0;
+    if (dyn_bytes) {
+        static bool raised_fast = false, raised_edge = false;   // per instantiation
+        bool& raised = fast ? raised_fast : raised_edge;
+        if (!raised) {
+            const void* fn = fast ? reinterpret_cast<const void*>(&gemm_mfma_kernel<Cfg, ALAY, BLAY, false, Epi>)
+                                  : reinterpret_cast<const void*>(&gemm_mfma_kernel<Cfg, ALAY, BLAY, true, Epi>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dyn_bytes);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+    }
     if (fast)
         hipLaunchKernelGGL((gemm_mfma_kernel<Cfg, ALAY, BLAY, false, Epi>), dim3(grid), dim3(Cfg::NTHREADS),
-                           0, stream, p, epi);
+                           dyn_bytes, stream, p, epi);
     else
         hipLaunchKernelGGL((gemm_mfma_kernel<Cfg, ALAY, BLAY, true, Epi>), dim3(grid), dim3(Cfg::NTHREADS),
-                           0, stream, p, epi);
+                           dyn_bytes, stream, p, epi);
     return hipGetLastError();
 }
 

@@ -210,9 +210,155 @@ int nmf_residual_api(dcp_handle* h, const T* Y, const T* mask, const T* X, const
     return DCP_OK;
 }
 
+// grads.py:108-125 / 143-160 on a minibatch: optional x update(s), then the two parts of the
+// D gradient as explicit [K,F] arrays (what serizel.py / kasai.py accumulate and mix).
+template <class T>
+int nmf_grads_api(dcp_handle* h, const T* Y, const T* mask, T* X, const T* D, int64_t N, int64_t F,
+                  int64_t K, int lik, int n_x_updates, T* grad_pos, T* grad_neg) {
+    DCP_TRY(check_nmf_args(h, Y, X, D, N, F, K, lik));
+    if (!grad_pos || !grad_neg) return fail(h, DCP_ERR_INVALID, "null gradient pointer");
+    if (n_x_updates < 0) return fail(h, DCP_ERR_INVALID, "negative update count");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    const bool masked = mask != nullptr;
+    const bool gram = (lik == DCP_LIK_L2 && !masked);
+    NmfShape<T> s{N, F, K, lik, masked};
+    const int64_t W = nmf_stats_width(F, K, lik, masked);
+    WsPlan plan;
+    nmf_plan_stats(plan, s, masked);
+    plan.add<T>((size_t)K * W);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    NmfStatsWs<T> ws;
+    DCP_TRY(nmf_carve_stats(h, ws, s, masked));
+    T* stats = ws_alloc<T>(h, (size_t)K * W);
+    if (!stats) return fail(h, DCP_ERR_INTERNAL, "nmf workspace plan mismatch");
+    const T* Ypre = Y;
+    if (masked) {
+        hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for(N * F)), dim3(256), 0, h->stream, Y,
+                           mask, (long)N, (long)F, (long)F, ws.Ym);
+        DCP_HIP_OK(h, hipGetLastError());
+        Ypre = ws.Ym;
+    }
+    for (int i = 0; i < n_x_updates; ++i)
+        DCP_TRY(nmf_stats<T>(h, Ypre, mask, X, X, D, s, stats, ws, 1));
+    DCP_TRY(nmf_stats<T>(h, Ypre, mask, X, X, D, s, stats, ws, 2));
+    // stats -> (pos, neg)
+    DCP_HIP_OK(h, hipMemcpy2DAsync(grad_pos, sizeof(T) * F, stats, sizeof(T) * W, sizeof(T) * F, K,
+                                   hipMemcpyDeviceToDevice, h->stream));
+    if (gram) {   // neg = (x^T x) D
+        GemmArgs<T> a;
+        a.A = stats + F; a.lda = W; a.B = D; a.ldb = F; a.M = (int)K; a.N = (int)F; a.K = (int)K;
+        a.tile = TILE_SMALL;
+        DCP_LAUNCH_OK(h, (gemm<FORM_NN>(h->stream, a, EpiStore<T>{grad_neg, (long)F})));
+    } else {
+        DCP_HIP_OK(h, hipMemcpy2DAsync(grad_neg, sizeof(T) * F, stats + F, sizeof(T) * W,
+                                       sizeof(T) * F, K, hipMemcpyDeviceToDevice, h->stream));
+    }
+    return DCP_OK;
+}
+
+// D_new = l2_strict(rule(D, P, Q)) and max|D - D_new| (host):
+//   alpha < 0 : D * max(P,0) / max(Q,eps)                         (grads.py:93)
+//   alpha >= 0: max(D * ((1-alpha) + alpha * P / max(Q,eps)), 0)  (kasai.py:77-78)
+template <class T>
+__global__ void __launch_bounds__(256) nmf_rule_kernel(const T* __restrict__ D, const T* __restrict__ P,
+                                                       const T* __restrict__ Q, long n, T alpha,
+                                                       T* __restrict__ U) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const T q = Q[i] > T(1.0e-15) ? Q[i] : T(1.0e-15);
+        T u;
+        if (alpha < T(0)) {
+            u = D[i] * (P[i] > T(0) ? P[i] : T(0)) / q;
+        } else {
+            u = D[i] * ((T(1) - alpha) + alpha * P[i] / q);
+            u = u > T(0) ? u : (u == u ? T(0) : u);
+        }
+        U[i] = u;
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) axpby_kernel(long n, T a, const T* __restrict__ x, T b,
+                                                    T* __restrict__ y) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
+        y[i] = a * x[i] + b * y[i];
+}
+
+template <class T>
+int nmf_apply_api(dcp_handle* h, const T* D, const T* P, const T* Q, double alpha, T* D_new, int64_t K,
+                  int64_t F, double* maxdiff) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!D || !P || !Q || !D_new || !maxdiff) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (K <= 0 || F <= 0) return fail(h, DCP_ERR_INVALID, "sizes must be positive");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    WsPlan plan;
+    nmf_plan_update<T>(plan, F, K);
+    plan.add<T>(2);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    NmfUpdateWs<T> wu;
+    DCP_TRY(nmf_carve_update(h, wu, F, K));
+    T* md = ws_alloc<T>(h, 2);
+    if (!md) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
+    hipLaunchKernelGGL((nmf_rule_kernel<T>), dim3(grid_for(K * F)), dim3(256), 0, h->stream, D, P, Q,
+                       (long)(K * F), (T)alpha, wu.U);
+    DCP_HIP_OK(h, hipGetLastError());
+    hipLaunchKernelGGL((row_normalize_kernel<T>), dim3((unsigned)K), dim3(256), 0, h->stream,
+                       (const T*)wu.U, (long)F, (long)F, 1, D, (long)F, D_new, (long)F, wu.rowmax,
+                       (T*)nullptr, (T*)nullptr, (T*)nullptr);
+    DCP_HIP_OK(h, hipGetLastError());
+    hipLaunchKernelGGL((final_max_kernel<T>), dim3(1), dim3(256), 0, h->stream, (const T*)wu.rowmax,
+                       (long)K, md);
+    DCP_HIP_OK(h, hipGetLastError());
+    void* hostv = nullptr;
+    DCP_TRY(host_scratch(h, 64, &hostv));
+    DCP_HIP_OK(h, hipMemcpyAsync(hostv, md, sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    *maxdiff = (double)(*reinterpret_cast<T*>(hostv));
+    return DCP_OK;
+}
+
+template <class T>
+int axpby_api(dcp_handle* h, int64_t n, double a, const T* x, double b, T* y) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!x || !y) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (n < 0) return fail(h, DCP_ERR_INVALID, "negative size");
+    if (n == 0) return DCP_OK;
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid_for(n)), dim3(256), 0, h->stream, (long)n, (T)a, x,
+                       (T)b, y);
+    DCP_HIP_OK(h, hipGetLastError());
+    return DCP_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int dcp_nmf_grads_f32(dcp_handle* h, const float* Y, const float* mask, float* X, const float* D,
+                      int64_t N, int64_t F, int64_t K, int likelihood, int n_x_updates,
+                      float* grad_pos, float* grad_neg) {
+    return nmf_grads_api<float>(h, Y, mask, X, D, N, F, K, likelihood, n_x_updates, grad_pos, grad_neg);
+}
+int dcp_nmf_grads_f64(dcp_handle* h, const double* Y, const double* mask, double* X, const double* D,
+                      int64_t N, int64_t F, int64_t K, int likelihood, int n_x_updates,
+                      double* grad_pos, double* grad_neg) {
+    return nmf_grads_api<double>(h, Y, mask, X, D, N, F, K, likelihood, n_x_updates, grad_pos, grad_neg);
+}
+int dcp_nmf_apply_f32(dcp_handle* h, const float* D, const float* P, const float* Q, double alpha,
+                      float* D_new, int64_t K, int64_t F, double* maxdiff) {
+    return nmf_apply_api<float>(h, D, P, Q, alpha, D_new, K, F, maxdiff);
+}
+int dcp_nmf_apply_f64(dcp_handle* h, const double* D, const double* P, const double* Q, double alpha,
+                      double* D_new, int64_t K, int64_t F, double* maxdiff) {
+    return nmf_apply_api<double>(h, D, P, Q, alpha, D_new, K, F, maxdiff);
+}
+int dcp_axpby_f32(dcp_handle* h, int64_t n, double a, const float* x, double b, float* y) {
+    return axpby_api<float>(h, n, a, x, b, y);
+}
+int dcp_axpby_f64(dcp_handle* h, int64_t n, double a, const double* x, double b, double* y) {
+    return axpby_api<double>(h, n, a, x, b, y);
+}
 
 int64_t dcp_nmf_mu_stats_width(int64_t F, int64_t K, int likelihood, int masked) {
     return nmf_stats_width(F, K, likelihood, masked != 0);

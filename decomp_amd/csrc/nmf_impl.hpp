@@ -162,7 +162,9 @@ inline int column_sums(dcp_handle* h, const T* a, long ld, long rows, long cols,
 // Ypre: Y already multiplied by the mask (or Y itself when there is no mask).
 template <class T>
 inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, T* Xout, const T* D,
-                     const NmfShape<T>& s, T* stats, NmfStatsWs<T>& w) {
+                     const NmfShape<T>& s, T* stats, NmfStatsWs<T>& w, int phases = 3) {
+    // phases: bit 0 = the x update (Xin -> Xout), bit 1 = the D-side sums (with Xout, or with
+    // Xin when the x update is skipped)
     hipStream_t st = h->stream;
     const int N = (int)s.N, F = (int)s.F, K = (int)s.K;
     const bool gram = (s.lik == DCP_LIK_L2 && !s.masked);
@@ -180,6 +182,8 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
         return DCP_OK;
     };
 
+    const T* X = Xin;
+    if (phases & 1) {
     // ---------------- x <- x * max(pos,0) / max(neg,eps) ----------------
     const T* xnum_A = Ypre;   // left operand of the positive-part GEMM (. D^T)
     const T* xden = w.Q;      // negative part
@@ -244,7 +248,9 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
             DCP_LAUNCH_OK(h, hipGetLastError());
         }
     }
-    const T* X = Xout;
+    X = Xout;
+    }
+    if (!(phases & 2)) return DCP_OK;
 
     // ---------------- local D-side sums with the NEW x ----------------
     GemmArgs<T> sa;

@@ -63,6 +63,8 @@ typedef TileCfg<256, 128, 16, 64, 64, 2> Cfg8wBig;       // 6: 8 waves, 256x128
 typedef TileCfg<256, 256, 16, 64, 64, 1> Cfg16w;         // 7: 16 waves, 256x256
 typedef TileCfg<128, 128, 16, 32, 64, 2> Cfg8wT;         // 8: 8 waves, 32x64 per wave
 typedef TileCfg<256, 128, 32, 64, 64, 1> Cfg8wBigDeep;   // 9: 8 waves, 256x128, BK = 32
+typedef TileCfg<256, 256, 32, 64, 64, 1> Cfg16wDeep;     // 10: 16 waves, 256x256, BK = 32 (128 KiB dynamic LDS)
+typedef TileCfg<256, 256, 32, 128, 64, 1> Cfg8wHuge;      // 11: 8 waves of 128x64, 256x256, BK = 32
 
 template <class Cfg, int FORM, class Epi>
 hipError_t hook_cfg(hipStream_t st, const GemmArgs<float>& a, const Epi& epi) {
@@ -90,6 +92,8 @@ hipError_t gemm_hook_launch(hipStream_t st, const GemmArgs<T>& a, int tile, cons
             case 7: return hook_cfg<Cfg16w, FORM>(st, a, epi);
             case 8: return hook_cfg<Cfg8wT, FORM>(st, a, epi);
             case 9: return hook_cfg<Cfg8wBigDeep, FORM>(st, a, epi);
+            case 10: return hook_cfg<Cfg16wDeep, FORM>(st, a, epi);
+            case 11: return hook_cfg<Cfg8wHuge, FORM>(st, a, epi);
             default: break;
         }
     }

@@ -1,13 +1,16 @@
 """Non-negative matrix factorisation -- drop-in for ``decomp.nmf`` on MI355X.
 
 Same entry point, argument meaning, return convention and error behaviour as the
-reference's decomp/nmf.py:16-80 for the full-batch multiplicative-update path
-(``minibatch=None, method='mu'``).  The iteration itself
+reference's decomp/nmf.py:16-113: the full-batch multiplicative update
+(``minibatch=None, method='mu'``) and the stochastic minibatch variants
+(decomp_amd/nmf_minibatch.py).  The full-batch iteration itself
 (decomp/nmf_methods/batch_mu.py:8-26 with the update rules of
 decomp/nmf_methods/grads.py:77-160) runs in libdecomp_hip.so: see
 include/decomp_hip.h ``dcp_nmf_mu_*`` and decomp_amd/csrc/nmf_impl.hpp.
 """
 import ctypes
+
+import numpy as np
 
 from . import _arrays, _hip
 from ._arrays import get_array_module
@@ -101,9 +104,27 @@ def solve(y, D, x=None, tol=1.0e-3, minibatch=None, maxiter=1000, method='mu',
             return it, _arrays.to_caller(D_dev, kind), _arrays.to_caller(x_dev, kind)
         raise NotImplementedError('Batch-NMF with {} algorithm is not yet '
                                   'implemented.'.format(method))
-    # stochastic variants (serizel.py, kasai.py) are outside this build's hot path
-    raise NotImplementedError('NMF with {} algorithm (minibatch) is not implemented in '
-                              'decomp_amd: only the full-batch \'mu\' path is.'.format(method))
+    # ---- stochastic variants: minibatch containers on the GPU (nmf.py:82-111) ----
+    from .utils.data import MinibatchData, NoneIterator
+    from . import nmf_minibatch
+    if method not in MINIBATCH_METHODS:
+        raise NotImplementedError('NMF with {} algorithm is not yet '
+                                  'implemented.'.format(method))
+    get_array_module(y, D, x_given, mask)
+    lik = _likelihood_code(likelihood)
+    if y_dev is None:
+        y_dev = _arrays.to_device(y, dev)
+    ybat = MinibatchData(y_dev, minibatch)
+    xbat = MinibatchData(x_dev, minibatch)
+    mbat = NoneIterator() if mask is None else MinibatchData(_arrays.to_device(mask, dev), minibatch)
+    rng = np.random.RandomState(random_seed)
+    if method in ['asg-mu', 'gsg-mu', 'asag-mu', 'gsag-mu']:
+        it, Dout, xout = nmf_minibatch.solve_serizel(ybat, D_dev, xbat, tol, minibatch, maxiter,
+                                                     method, lik, mbat, rng, **kwargs)
+    else:
+        it, Dout, xout = nmf_minibatch.solve_kasai(ybat, D_dev, xbat, tol, minibatch, maxiter,
+                                                   method, lik, mbat, rng, **kwargs)
+    return it, _arrays.to_caller(Dout, kind), _arrays.to_caller(xout, kind)
 
 
 def _run_mu(y, mask, x, D, lik, tol, maxiter, resid_trace=None):

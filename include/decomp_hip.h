@@ -142,6 +142,28 @@ int dcp_nmf_mu_update_f64(dcp_handle* h, const double* stats, const double* D, d
                           int64_t F, int64_t K, int likelihood, int masked,
                           double* maxdiff_dev, double* maxdiff_next);
 
+/* Building blocks of the stochastic MU variants (decomp/nmf_methods/serizel.py:36-165,
+ * kasai.py:36-88), which are host loops over minibatches around the same gradients:
+ *   dcp_nmf_grads_*: n_x_updates times  x_mb <- x_mb o max(gx+,0)/max(gx-,1e-15)  in place
+ *                    (serizel.py:46-49, kasai.py:63-67), then the two parts of the D gradient
+ *                    (grads.py:117-125, 152-160) of that minibatch into grad_pos / grad_neg [K,F].
+ *   dcp_nmf_apply_*: D_new = l2_strict(rule) and max|D - D_new| to the host:
+ *                    alpha <  0: D o max(P,0)/max(Q,1e-15)                 (serizel.py:54-57)
+ *                    alpha >= 0: max(D o ((1-alpha) + alpha P/max(Q,1e-15)), 0)  (kasai.py:77-78)
+ *   dcp_axpby_*    : y = a x + b y  (gradient averaging serizel.py:95-96, kasai.py:74-75). */
+int dcp_nmf_grads_f32(dcp_handle* h, const float* Y, const float* mask, float* X, const float* D,
+                      int64_t N, int64_t F, int64_t K, int likelihood, int n_x_updates,
+                      float* grad_pos, float* grad_neg);
+int dcp_nmf_grads_f64(dcp_handle* h, const double* Y, const double* mask, double* X, const double* D,
+                      int64_t N, int64_t F, int64_t K, int likelihood, int n_x_updates,
+                      double* grad_pos, double* grad_neg);
+int dcp_nmf_apply_f32(dcp_handle* h, const float* D, const float* P, const float* Q, double alpha,
+                      float* D_new, int64_t K, int64_t F, double* maxdiff);
+int dcp_nmf_apply_f64(dcp_handle* h, const double* D, const double* P, const double* Q, double alpha,
+                      double* D_new, int64_t K, int64_t F, double* maxdiff);
+int dcp_axpby_f32(dcp_handle* h, int64_t n, double a, const float* x, double b, float* y);
+int dcp_axpby_f64(dcp_handle* h, int64_t n, double a, const double* x, double b, double* y);
+
 /* ||(Y - X D) o mask||_F (parity metric of SURVEY 8d; mask nullable). */
 int dcp_nmf_residual_f32(dcp_handle* h, const float* Y, const float* mask, const float* X,
                          const float* D, int64_t N, int64_t F, int64_t K, double* out);

@@ -16,4 +16,4 @@ Parity pinning: the restatement is checked against the real reference
 ``tests/golden/``; see ``tests/test_oracle_golden.py``.
 """
 
-from . import common, nmf, lasso, dictionary_learning  # noqa: F401
+from . import common, nmf, nmf_minibatch, lasso, dictionary_learning  # noqa: F401

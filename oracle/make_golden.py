@@ -110,6 +110,49 @@ def gen_nmf(ref, out):
     print('nmf: %d cases' % len(cases))
 
 
+def gen_nmf_minibatch(ref, out):
+    """Stochastic variants (tests/test_nmf.py:105-152 shapes: 1001 x 20, K = 3,
+    minibatch 30), a few epochs with tol = 0 so the whole trajectory is pinned."""
+    data = {}
+    cases = []
+    methods = ['asg-mu', 'gsg-mu', 'asag-mu', 'gsag-mu', 'svrmu', 'svrmu-acc']
+    for dtype in (np.float64, np.float32):
+        for lik in ('l2', 'kl'):
+            if dtype == np.float32 and lik == 'kl':
+                continue
+            y, D0, mask = nmf_inputs(0, 1001, 20, 3, dtype, lik)
+            base = 'nmfmb_%s_%s' % (np.dtype(dtype).name, lik)
+            data[base + '/y'] = y
+            data[base + '/D0'] = D0
+            data[base + '/mask'] = mask
+            for method in methods:
+                for use_mask in (False, True):
+                    for maxiter in (3,):
+                        it, D, x = ref.nmf.solve(
+                            y.copy(), D0.copy(), x=None, tol=0.0, minibatch=30,
+                            maxiter=maxiter, method=method, likelihood=lik,
+                            mask=mask.copy() if use_mask else None, random_seed=0)
+                        name = '%s/%s/%s/it%d' % (base, method, 'mask' if use_mask else 'nomask',
+                                                  maxiter)
+                        cases.append(name)
+                        data[name + '/it'] = np.int64(it)
+                        data[name + '/D'] = D
+                        data[name + '/x'] = x
+            # one converging run per method (the old-D-on-convergence quirk)
+            for method in methods:
+                it, D, x = ref.nmf.solve(y.copy(), D0.copy(), x=None, tol=3.0e-2, minibatch=30,
+                                         maxiter=30, method=method, likelihood=lik, mask=None,
+                                         random_seed=0)
+                name = '%s/%s/conv' % (base, method)
+                cases.append(name)
+                data[name + '/it'] = np.int64(it)
+                data[name + '/D'] = D
+                data[name + '/x'] = x
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(out, 'nmf_minibatch_golden.npz'), **data)
+    print('nmf minibatch: %d cases' % len(cases))
+
+
 # ---------------------------------------------------------------- LASSO ----
 def lasso_inputs(seed, batch_shape, K, F, kind):
     """Generators of tests/test_lasso.py:160-250 (vector / matrix / tensor;
@@ -258,6 +301,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     ref = load_reference(args.ref)
     gen_nmf(ref, args.out)
+    gen_nmf_minibatch(ref, args.out)
     gen_lasso(ref, args.out)
     gen_dl(ref, args.out)
     return 0

@@ -152,3 +152,28 @@ def test_dictionary_learning_all_cases(golden_dir):
         assert it == int(g[name + '/it']), name
         assert _close(D, g[name + '/D'], 1.0e-9), name
         assert _close(x, g[name + '/x'], 1.0e-9), name
+
+
+# ------------------------------------------------------- stochastic MU NMF -----
+def test_nmf_minibatch_all_cases(golden_dir):
+    from oracle import nmf_minibatch as omb
+    g = _load(golden_dir, 'nmf_minibatch_golden.npz')
+    cases = [str(c) for c in g['cases']]
+    assert len(cases) == 54
+    for name in cases:
+        parts = name.split('/')
+        base, method = parts[0], parts[1]
+        y, D0, mask = g[base + '/y'], g[base + '/D0'], g[base + '/mask']
+        lik = 'kl' if base.endswith('_kl') else 'l2'
+        if parts[2] == 'conv':
+            it, D, x = omb.solve(y.copy(), D0.copy(), tol=3.0e-2, minibatch=30, maxiter=30,
+                                 method=method, likelihood=lik, random_seed=0)
+        else:
+            it, D, x = omb.solve(y.copy(), D0.copy(), tol=0.0, minibatch=30,
+                                 maxiter=int(parts[3][2:]), method=method, likelihood=lik,
+                                 mask=mask.copy() if parts[2] == 'mask' else None, random_seed=0)
+        tol = 1.0e-9 if y.dtype == np.float64 else 2.0e-4
+        if y.dtype == np.float64 or parts[2] != 'conv':
+            assert it == int(g[name + '/it']), name
+            assert _close(D, g[name + '/D'], tol), name
+            assert _close(x, g[name + '/x'], tol), name
