@@ -8,9 +8,7 @@
 //
 // The statistics product x^H [y | x] is one split-K GEMM (the same [K, F+K] layout that the
 // data-parallel driver all-reduces).  The atom sweep is inherently sequential in k (every
-// atom needs the full-row norm of the previous one): it runs as K+1 small launches, each
-// finalising atom k-1 (norm from per-workgroup partials) and forming the un-normalised atom
-// k for a 64-column stripe per workgroup, 16 waves splitting the K-long contraction.
+// atom needs the full-row norm of the previous one): see atom_block_kernel below.
 #pragma once
 #include "lasso_impl.hpp"
 
@@ -40,66 +38,127 @@ __global__ void __launch_bounds__(256) dict_accumulate_kernel(const T* __restric
     }
 }
 
-// One launch per atom (k = 0..K; the last one only finalises atom K-1).
-// grid = ceil(F / 64) workgroups of 1024 threads (16 waves); lane = column.
-template <class T>
-__global__ void __launch_bounds__(1024) atom_step_kernel(int k, int K, long F, const T* __restrict__ A,
-                                                         const T* __restrict__ B, T* __restrict__ Dnew,
-                                                         real_t<T>* __restrict__ partial /* [2][grid] */) {
-    typedef real_t<T> R;
-    __shared__ T s_part[16][64];
-    __shared__ T s_fresh[64];
-    __shared__ R s_red[64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long f = (long)blockIdx.x * 64 + lane;
-    const bool fok = f < F;
-    const int G = gridDim.x;
+// The atom sweep (dictionary_learning.py:154-159) is sequential in k: atom k needs the
+// full-row norm of every earlier atom.  It runs in super blocks of SB = 64 atoms:
+//   (1) R = B_blk - A[blk, :] . D_cur            one MFMA GEMM per 64 atoms
+//       (D_cur: rows < k0 already new, the rest old)
+//   (2) ONE 512-thread workgroup (8 waves: 256 registers per thread) walks the 64 atoms in
+//       sub-blocks of BR: thread t owns CC columns of F and
+//       keeps dD_j = D_new[j] - D_old[j] of the sub-block's finished atoms in registers, so
+//         u_k = (R_k - sum_{j<k in sub} A_kj dD_j) / (A_kk + 1e-15) + D_old[k]
+//       needs no memory traffic and the row norm is a block reduction (no grid sync); after
+//       a sub-block its dD is folded into the R rows of the super block still to come.
+// 2 launches per 64 atoms instead of one launch (and a K-long strided contraction) per atom.
+constexpr int kAtomSB = 64;
 
-    // ---- finalise atom k-1: D_new[k-1] = u / sqrt(max(|u|^2, 1))   (normalize.py:2-10) ----
-    if (k > 0) {
-        if (wave == 0) {
-            R tot = 0;
-            const R* p = partial + (long)((k - 1) & 1) * G;
-            for (int g = 0; g < G; ++g) tot += p[g];      // same order in every workgroup
-            const R nrm = sqrt(tot > R(1) ? tot : R(1));
-            T u = zero_of<T>();
-            if (fok) {
-                u = Dnew[(long)(k - 1) * F + f];
-                if constexpr (scalar_traits<T>::is_complex) { u.re = u.re / nrm; u.im = u.im / nrm; }
-                else u = u / nrm;
-                Dnew[(long)(k - 1) * F + f] = u;
+template <class T, int BR, int CC>
+__global__ void __launch_bounds__(512) atom_super_kernel(int k0, int ns, int K, long F,
+                                                          const T* __restrict__ A,
+                                                          T* __restrict__ Rs /* [ns, F] */,
+                                                          T* __restrict__ Dnew) {
+    typedef real_t<T> R_t;
+    __shared__ T s_a[kAtomSB][BR + 1];   // A[k0 + r][k0 + i0 + j] for the rows r still to do
+    __shared__ R_t s_red[2][8];          // per-wave partial norms, double buffered by atom parity
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i0 = 0; i0 < ns; i0 += BR) {
+        const int nb = min(BR, ns - i0);
+        __syncthreads();
+        for (int e = tid; e < (ns - i0) * BR; e += 512) {
+            const int r = e / BR, j = e % BR;     // row i0 + r of the super block
+            s_a[r][j] = (j < nb) ? A[(long)(k0 + i0 + r) * K + (k0 + i0 + j)] : zero_of<T>();
+        }
+        __syncthreads();
+        T dD[BR][CC];   // statically indexed (loops fully unrolled): stays in registers
+        // software pipeline: the residual / old-dictionary values of atom i+1 are in flight
+        // while atom i is reduced (the barrier would otherwise expose their latency)
+        T rcur[CC], dcur[CC], rnxt[CC], dnxt[CC];
+#pragma clang loop unroll(full)
+        for (int c = 0; c < CC; ++c) {
+            const long f = tid + 512L * c;
+            rcur[c] = (f < F) ? Rs[(long)i0 * F + f] : zero_of<T>();
+            dcur[c] = (f < F) ? Dnew[(long)(k0 + i0) * F + f] : zero_of<T>();
+        }
+#pragma clang loop unroll(full)
+        for (int i = 0; i < BR; ++i) {
+            if (i >= nb) {   // nb is uniform
+#pragma clang loop unroll(full)
+                for (int c = 0; c < CC; ++c) dD[i][c] = zero_of<T>();
+                continue;
             }
-            s_fresh[lane] = u;
-        }
-    }
-    __syncthreads();
-    if (k >= K) return;
-
-    // ---- u_k = (B_k - A_k . D_new) / (A_kk + 1e-15) + D_new[k]   (dictionary_learning.py:156) ----
-    T acc = zero_of<T>();
-    const T* arow = A + (long)k * K;
-    for (int j = wave; j < K; j += 16) {
-        T d;
-        if (j == k - 1) d = s_fresh[lane];            // just normalised above (not yet re-read)
-        else d = fok ? Dnew[(long)j * F + f] : zero_of<T>();
-        acc = madd(acc, arow[j], d);
-    }
-    s_part[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0) {
-        T dot = s_part[0][lane];
+            const int k = k0 + i0 + i;
+            if (i + 1 < nb) {
+#pragma clang loop unroll(full)
+                for (int c = 0; c < CC; ++c) {
+                    const long f = tid + 512L * c;
+                    rnxt[c] = (f < F) ? Rs[(long)(i0 + i + 1) * F + f] : zero_of<T>();
+                    dnxt[c] = (f < F) ? Dnew[(long)(k + 1) * F + f] : zero_of<T>();
+                }
+            }
+            T u[CC];
+            R_t part = 0;
+            // 1 / (A_kk + 1e-15) once per atom (a reciprocal-multiply instead of CC divisions:
+            // this single-workgroup kernel is VALU-issue bound; <= 1 ulp from a true division)
+            const T rden = div_scalar(from_real<T>(R_t(1)), add(s_a[i][i], from_real<T>(R_t(1.0e-15))));
+#pragma clang loop unroll(full)
+            for (int c = 0; c < CC; ++c) {
+                T acc = rcur[c];
+#pragma clang loop unroll(full)
+                for (int j = 0; j < BR; ++j)
+                    if (j < i) acc = sub(acc, mul(s_a[i][j], dD[j][c]));
+                u[c] = add(mul(acc, rden), dcur[c]);           // dcur = D_old[k] (row k untouched)
+                const long f = tid + 512L * c;
+                if (f >= F) u[c] = zero_of<T>();
+                part += abs2(u[c]);
+            }
+            part = wave_sum(part);
+            if (lane == 0) s_red[i & 1][wave] = part;
+            __syncthreads();                  // the only barrier per atom
+            R_t tot = (lane < 8) ? s_red[i & 1][lane] : R_t(0);
 #pragma unroll
-        for (int w = 1; w < 16; ++w) dot = add(dot, s_part[w][lane]);
-        T u = zero_of<T>();
-        if (fok) {
-            const T dk = Dnew[(long)k * F + f];   // still D[k]: row k is untouched so far
-            const T den = add(arow[k], from_real<T>(R(1.0e-15)));
-            u = add(div_scalar(sub(B[(long)k * F + f], dot), den), dk);
-            Dnew[(long)k * F + f] = u;
+            for (int o = 4; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            tot = __shfl(tot, 0, 64);         // same summation order in every wave
+            const R_t rnrm = R_t(1) / sqrt(tot > R_t(1) ? tot : R_t(1));   // normalize.py:2-10 (l2)
+#pragma clang loop unroll(full)
+            for (int c = 0; c < CC; ++c) {
+                const long f = tid + 512L * c;
+                const T dn = scale(u[c], rnrm);
+                dD[i][c] = sub(dn, dcur[c]);
+                if (f < F) Dnew[(long)k * F + f] = dn;
+                rcur[c] = rnxt[c];
+                dcur[c] = dnxt[c];
+            }
         }
-        R v = fok ? abs2(u) : R(0);
-        v = wave_sum(v);
-        if (lane == 0) partial[(long)(k & 1) * G + blockIdx.x] = v;
+        // fold this sub-block into the residual rows still to come (own columns only);
+        // 4 rows at a time so that 4*CC loads are in flight per thread
+        constexpr int RB = 4;
+        for (int r0 = nb; r0 < ns - i0; r0 += RB) {
+            T acc[RB][CC];
+#pragma clang loop unroll(full)
+            for (int q = 0; q < RB; ++q)
+#pragma clang loop unroll(full)
+                for (int c = 0; c < CC; ++c) {
+                    const long f = tid + 512L * c;
+                    acc[q][c] = (f < F && r0 + q < ns - i0) ? Rs[(long)(i0 + r0 + q) * F + f]
+                                                            : zero_of<T>();
+                }
+#pragma clang loop unroll(full)
+            for (int q = 0; q < RB; ++q) {
+                const int r = (r0 + q < ns - i0) ? (r0 + q) : r0;
+#pragma clang loop unroll(full)
+                for (int j = 0; j < BR; ++j) {
+                    const T a = s_a[r][j];
+#pragma clang loop unroll(full)
+                    for (int c = 0; c < CC; ++c) acc[q][c] = sub(acc[q][c], mul(a, dD[j][c]));
+                }
+            }
+#pragma clang loop unroll(full)
+            for (int q = 0; q < RB; ++q)
+#pragma clang loop unroll(full)
+                for (int c = 0; c < CC; ++c) {
+                    const long f = tid + 512L * c;
+                    if (f < F && r0 + q < ns - i0) Rs[(long)(i0 + r0 + q) * F + f] = acc[q][c];
+                }
+        }
     }
 }
 
@@ -134,8 +193,9 @@ struct DictWs {
     typedef real_t<T> R;
     T* slabs = nullptr;
     size_t slab_count = 0;
-    R* partial = nullptr;   // [2][G] atom norms / max partials
+    R* partial = nullptr;   // max|dD| partials
     R* scal = nullptr;
+    T* Rblk = nullptr;      // [64, F] residual rows of the atom super block being processed
 };
 
 template <class T>
@@ -175,12 +235,39 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
                        stats, (long)K, (long)F, beta, A, B);
     DCP_LAUNCH_OK(h, hipGetLastError());
     DCP_HIP_OK(h, hipMemcpyAsync(Dnew, D, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice, st));
-    const int G = (int)((F + 63) / 64);
-    for (int k = 0; k <= (int)K; ++k) {
-        hipLaunchKernelGGL((atom_step_kernel<T>), dim3(G), dim3(1024), 0, st, k, (int)K, (long)F,
-                           (const T*)A, (const T*)B, Dnew, w.partial);
+    // blocked atom sweep
+    const int CCneed = (int)((F + 511) / 512);
+    if (CCneed > 16) return fail(h, DCP_ERR_UNSUPPORTED, "dictionary update: n_channels > 8192");
+    for (int k0 = 0; k0 < (int)K; k0 += kAtomSB) {
+        const int ns = ((int)K - k0) < kAtomSB ? ((int)K - k0) : kAtomSB;
+        {   // R = B_blk - A[blk, :] . D_cur
+            GemmArgs<T> a;
+            a.A = A + (long)k0 * K; a.lda = K; a.B = Dnew; a.ldb = F;
+            a.M = ns; a.N = (int)F; a.K = (int)K;
+            a.tile = TILE_SMALL;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiSubFrom<T>{B + (long)k0 * F, (long)F, w.Rblk, (long)F})));
+        }
+        // sub-block height: the sub-block's dD rows stay within ~64 registers per thread
+#define DCP_ATOM_LAUNCH(BRV, CCV)                                                                   \
+    hipLaunchKernelGGL((atom_super_kernel<T, BRV, CCV>), dim3(1), dim3(512), 0, st, k0, ns, (int)K, \
+                       (long)F, (const T*)A, w.Rblk, Dnew)
+        // BR x CC (x2 for complex) dD registers per thread <= 64: no spills at 256 regs/thread
+        if constexpr (scalar_traits<T>::is_complex) {
+            if (CCneed <= 1) DCP_ATOM_LAUNCH(32, 1);
+            else if (CCneed <= 2) DCP_ATOM_LAUNCH(16, 2);
+            else if (CCneed <= 4) DCP_ATOM_LAUNCH(8, 4);
+            else if (CCneed <= 8) DCP_ATOM_LAUNCH(4, 8);
+            else DCP_ATOM_LAUNCH(2, 16);
+        } else {
+            if (CCneed <= 1) DCP_ATOM_LAUNCH(32, 1);
+            else if (CCneed <= 2) DCP_ATOM_LAUNCH(32, 2);
+            else if (CCneed <= 4) DCP_ATOM_LAUNCH(16, 4);
+            else if (CCneed <= 8) DCP_ATOM_LAUNCH(8, 8);
+            else DCP_ATOM_LAUNCH(4, 16);
+        }
+#undef DCP_ATOM_LAUNCH
+        DCP_LAUNCH_OK(h, hipGetLastError());
     }
-    DCP_LAUNCH_OK(h, hipGetLastError());
     const int mb = grid_for((long)K * F, 256);
     hipLaunchKernelGGL((maxabsdiff_partial_kernel<T>), dim3(mb), dim3(256), 0, st, D, (const T*)Dnew,
                        (long)K * F, w.partial);

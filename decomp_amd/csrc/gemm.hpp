@@ -31,6 +31,7 @@ struct GemmArgs {
     int klen = 0;     // reduction length per split (set by plan_splits)
     bool conjA = false, conjB = false;  // complex only
     int tile = TILE_AUTO;
+    bool split_planned = false;  // set by plan_splits: tile tiers may count on split-K
 };
 
 // MFMA tile tiers (BM, BN, BK, WM, WN, min waves/SIMD).  Measured on MI355X (tools/gemm_sweep.py,
@@ -41,14 +42,16 @@ struct GemmArgs {
 typedef TileCfg<256, 256, 16, 64, 64, 1> CfgHuge;      // 16 waves, 64 KiB LDS
 typedef TileCfg<128, 128, 16, 64, 64, 2> CfgLarge;     // 4 waves, 32 KiB LDS -> 4 WG/CU
 typedef TileCfg<64, 64, 16, 32, 32, 2> CfgSmall;
+typedef TileCfg<32, 128, 32, 32, 32, 2> CfgFlat;       // <= 32 output rows (atom-block residuals)
 
-enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2 };
+enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2, TIER_FLAT = 3 };
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 inline void tier_dims(int tier, int& bm, int& bn) {
     if (tier == TIER_HUGE) { bm = CfgHuge::BM; bn = CfgHuge::BN; }
     else if (tier == TIER_LARGE) { bm = CfgLarge::BM; bn = CfgLarge::BN; }
+    else if (tier == TIER_FLAT) { bm = CfgFlat::BM; bn = CfgFlat::BN; }
     else { bm = 64; bn = 64; }
 }
 
@@ -56,19 +59,20 @@ inline void tier_dims(int tier, int& bm, int& bn) {
 // launch): the largest tile that still gives the chip enough workgroups, counting the splits
 // a deep reduction allows.
 template <int FORM>
-inline int pick_tier(int M, int N, int K, int tile_sel) {
+inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
     if (tile_sel == TILE_SMALL) return TIER_SMALL;
     if (tile_sel == TILE_LARGE) return TIER_LARGE;
     if (tile_sel == TILE_HUGE) return FORM == FORM_TN ? TIER_LARGE : TIER_HUGE;
-    long splits = K / 512;
+    long splits = will_split ? K / 512 : 1;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
     if (FORM != FORM_TN) {
         const long wh = (long)ceil_div(M, CfgHuge::BM) * ceil_div(N, CfgHuge::BN);
         if (M >= 256 && N >= 256 && wh * splits >= 192) return TIER_HUGE;
     }
+    // un-split products want at least two 4-wave workgroups per CU to hide latency
     const long wl = (long)ceil_div(M, CfgLarge::BM) * ceil_div(N, CfgLarge::BN);
-    if (wl * splits >= 256) return TIER_LARGE;
+    if (wl * splits >= (will_split ? 256 : 512)) return TIER_LARGE;
     return TIER_SMALL;
 }
 
@@ -77,7 +81,8 @@ inline int pick_tier(int M, int N, int K, int tile_sel) {
 template <int FORM, class T>
 inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits) {
     int bm = 64, bn = 64;
-    if (std::is_same<T, float>::value) tier_dims(pick_tier<FORM>(a.M, a.N, a.K, a.tile), bm, bn);
+    a.split_planned = true;
+    if (std::is_same<T, float>::value) tier_dims(pick_tier<FORM>(a.M, a.N, a.K, a.tile, true), bm, bn);
     const int n1 = a.B2 != nullptr ? a.n_b1 : a.N;
     const long tiles = (long)ceil_div(a.M, bm) * (ceil_div(n1, bn) + ceil_div(a.N - n1, bn));
     const long kblocks = ceil_div(a.K > 0 ? a.K : 1, 16);
@@ -108,7 +113,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
         constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
         constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
-        const int tier = pick_tier<FORM>(a.M, a.N, a.K, a.tile);
+        const int tier = pick_tier<FORM>(a.M, a.N, a.K, a.tile, a.split_planned);
         if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL, Epi>(stream, p, epi);
         if constexpr (FORM != FORM_TN) {
             if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL, Epi>(stream, p, epi);

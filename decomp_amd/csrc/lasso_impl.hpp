@@ -147,16 +147,30 @@ __global__ void __launch_bounds__(256) col_scale_kernel(const T* __restrict__ x,
     }
 }
 
-// Linv = 1 / max_j sum_i |AAt[i, j]|   (eigen.py:20, lasso.py:286).  One workgroup.
+// Linv = 1 / max_j sum_i |AAt[i, j]|   (eigen.py:20, lasso.py:286), two stages:
+// stage 1: partial[s, j] = sum over a stripe of rows of |AAt[i, j]|  (coalesced along j)
 template <class T>
-__global__ void __launch_bounds__(256) gershgorin_inv_kernel(const T* __restrict__ AAt, long K,
-                                                             real_t<T>* __restrict__ Linv) {
+__global__ void __launch_bounds__(256) colabs_partial_kernel(const T* __restrict__ a, long K,
+                                                             long rows_per_blk,
+                                                             real_t<T>* __restrict__ partial) {
     typedef real_t<T> R;
+    const long r0 = blockIdx.y * rows_per_blk;
+    const long r1 = min(K, r0 + rows_per_blk);
+    for (long c = blockIdx.x * 256L + threadIdx.x; c < K; c += (long)gridDim.x * 256L) {
+        R acc = 0;
+        for (long r = r0; r < r1; ++r) acc += absval(a[r * K + c]);
+        partial[blockIdx.y * K + c] = acc;
+    }
+}
+// stage 2 (one workgroup): column sums of the stripes in order, max over columns, inverse.
+template <class R>
+__global__ void __launch_bounds__(256) gershgorin_finish_kernel(const R* __restrict__ partial, long K,
+                                                                int stripes, R* __restrict__ Linv) {
     __shared__ R sh[4];
     R best = 0;
     for (long j = threadIdx.x; j < K; j += 256) {
         R acc = 0;
-        for (long i = 0; i < K; ++i) acc += absval(AAt[i * K + j]);
+        for (int s = 0; s < stripes; ++s) acc += partial[(long)s * K + j];
         best = (acc > best || acc != acc) ? acc : best;
     }
     R m = block_max_256(best, sh);
@@ -333,6 +347,7 @@ struct LassoWs {
     R* mbar = nullptr;   // [F]
     R* part = nullptr;   // column-sum partials [64, F]
     R* scal = nullptr;   // [4]: Linv, nvalid
+    R* gpart = nullptr;  // [64, K] Gershgorin column-sum stripes
     int* flag = nullptr;
     size_t slab_count = 0;
 };
@@ -354,6 +369,7 @@ inline void lasso_plan(WsPlan& p, int64_t N, int64_t F, int64_t K, int mask_ndim
     p.add<R>((size_t)F);
     p.add<R>((size_t)64 * F);
     p.add<R>(4);
+    p.add<R>((size_t)64 * K);
     p.add<int>(4);
 }
 
@@ -379,9 +395,10 @@ inline int lasso_carve(dcp_handle* h, LassoWs<T>& w, int64_t N, int64_t F, int64
     w.mbar = ws_alloc<R>(h, (size_t)F);
     w.part = ws_alloc<R>(h, (size_t)64 * F);
     w.scal = ws_alloc<R>(h, 4);
+    w.gpart = ws_alloc<R>(h, (size_t)64 * K);
     w.flag = ws_alloc<int>(h, 4);
     if (!w.An || !w.yAt || !w.AAt || !w.slabs || !w.xb[3] || !w.s || !w.alphak || !w.tolk ||
-        !w.akk || !w.rowscale || !w.mbar || !w.part || !w.scal || !w.flag ||
+        !w.akk || !w.rowscale || !w.mbar || !w.part || !w.scal || !w.gpart || !w.flag ||
         (mask_ndim != 0 && !w.Ym) || (mask_ndim == 2 && (!w.Am || !w.T1)) ||
         (method == DCP_LASSO_CD && mask_ndim != 2 && !w.G))
         return fail(h, DCP_ERR_INTERNAL, "lasso workspace plan mismatch");
@@ -556,9 +573,16 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         } else {
             DCP_TRY(gram_kk<T>(h, w.An, w.An, K, F, w, w.AAt));
         }
-        hipLaunchKernelGGL((gershgorin_inv_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)w.AAt,
-                           (long)K, w.scal);
-        DCP_LAUNCH_OK(h, hipGetLastError());
+        {
+            const int stripes = K >= 64 ? 64 : K;
+            const long rows_per = (K + stripes - 1) / stripes;
+            hipLaunchKernelGGL((colabs_partial_kernel<T>), dim3(grid_for(K, 64), stripes), dim3(256), 0,
+                               st, (const T*)w.AAt, (long)K, rows_per, w.gpart);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+            hipLaunchKernelGGL((gershgorin_finish_kernel<R>), dim3(1), dim3(256), 0, st,
+                               (const R*)w.gpart, (long)K, stripes, w.scal);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+        }
 
         // Buffer roles (pointers rotate over the four [N,K] buffers):
         //   P = the iterate the stop test compares with (the reference's x0)

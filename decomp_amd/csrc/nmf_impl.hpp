@@ -58,7 +58,7 @@ inline int nmf_xupdate_splits(int64_t N, int64_t F, int64_t K, GemmArgs<T>& pg) 
     pg.M = (int)N; pg.N = (int)K; pg.K = (int)F;
     pg.tile = TILE_AUTO;
     int bm = 64, bn = 64;
-    if (std::is_same<T, float>::value) tier_dims(pick_tier<FORM_NT>(pg.M, pg.N, pg.K, TILE_AUTO), bm, bn);
+    if (std::is_same<T, float>::value) tier_dims(pick_tier<FORM_NT>(pg.M, pg.N, pg.K, TILE_AUTO, true), bm, bn);
     const long tiles = (long)ceil_div(N, bm) * ceil_div(K, bn);
     const long enough = (bm == 256) ? 192 : 512;
     if (tiles >= enough || F < 1024) {
