@@ -64,6 +64,10 @@ SIGNATURES = {
     'dcp_dict_update_c128': (_c_int, [_c_vp, _c_vp, _c_f64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_step_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
     'dcp_gather_rows_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_dict_mask_step_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_dict_mask_step_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_dict_mask_step_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_dict_mask_step_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
     'dcp_nmf_grads_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp]),
     'dcp_nmf_grads_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp]),
     'dcp_nmf_apply_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_f64, _c_vp, _c_i64, _c_i64, _P(_c_f64)]),

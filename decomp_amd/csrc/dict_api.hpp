@@ -130,6 +130,82 @@ inline int dict_step_api(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, T
     return DCP_OK;
 }
 
+// dictionary_learning.py:192-225 for one minibatch with a mask (solve_cd_mask).
+template <class T>
+inline int dict_mask_step_api(dcp_handle* h, const T* Y, const real_t<T>* M, T* X, const T* D, T* Dnew,
+                              T* A3, T* B, int64_t Nb, int64_t F, int64_t K, double beta, double alpha,
+                              int lasso_method, int lasso_iter, double lasso_tol, double* maxdiff_host,
+                              int* lasso_it) {
+    typedef real_t<T> R;
+    DCP_TRY(dict_check<T>(h, Y, X, D, Nb, F, K));
+    if (!M || !Dnew || !A3 || !B || !maxdiff_host) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (lasso_method < DCP_LASSO_ISTA || lasso_method > DCP_LASSO_CD)
+        return fail(h, DCP_ERR_INVALID, "bad lasso method");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    WsPlan plan;
+    lasso_plan<T>(plan, Nb, F, K, 2, lasso_method);
+    dict_plan_extra<T>(plan, Nb, F, K);
+    plan.add<T>((size_t)Nb * F);   // y o m
+    plan.add<T>((size_t)K * F);    // x^H (y o m)
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    LassoWs<T> lw;
+    DictWs<T> dw;
+    DCP_TRY(lasso_carve<T>(h, lw, Nb, F, K, 2, lasso_method));
+    DCP_TRY(dict_carve_extra<T>(h, dw, Nb, F, K));
+    T* Ym = ws_alloc<T>(h, (size_t)Nb * F);
+    T* sB = ws_alloc<T>(h, (size_t)K * F);
+    if (!Ym || !sB) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
+    int it = 0;
+    if constexpr (scalar_traits<T>::is_complex) {
+        DCP_TRY((lasso_solve<T, PROX_COMPLEX>(h, Y, M, 2, D, X, Nb, F, K, (R)alpha, (R)lasso_tol,
+                                              lasso_iter, lasso_method, &it, lw)));
+    } else {
+        DCP_TRY((lasso_solve<T, PROX_REAL>(h, Y, M, 2, D, X, Nb, F, K, (R)alpha, (R)lasso_tol,
+                                           lasso_iter, lasso_method, &it, lw)));
+    }
+    if (lasso_it) *lasso_it = it;
+    // A3 <- beta A3 + x^H (x (x) m)
+    hipLaunchKernelGGL((dict_mask_gram_kernel<T>), dim3((unsigned)F), dim3(256), 0, st, (const T*)X, M,
+                       (long)Nb, (long)F, (int)K, (R)beta, A3);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    // B <- beta B + x^H (y o m)
+    hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for((long)Nb * F)), dim3(256), 0, st, Y, M,
+                       (long)Nb, (long)F, (long)F, Ym);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    {
+        GemmArgs<T> a;
+        a.A = X; a.lda = K; a.B = Ym; a.ldb = F; a.M = (int)K; a.N = (int)F; a.K = (int)Nb;
+        a.conjA = true;
+        plan_splits<FORM_TN>(a, kSplitTarget, kMaxSplits);
+        if ((size_t)a.ksplits * K * F > dw.slab_count) return fail(h, DCP_ERR_INTERNAL, "dict slab plan");
+        DCP_LAUNCH_OK(h, (gemm<FORM_TN>(st, a, EpiSlab<T>{dw.slabs, (long)F, (long)K * F})));
+        hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * F)), dim3(256), 0, st,
+                           dw.slabs, (long)K * F, a.ksplits, (long)K * F, sB);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        hipLaunchKernelGGL((scale_add_kernel<T>), dim3(grid_for((long)K * F)), dim3(256), 0, st,
+                           (long)K * F, (R)beta, (const T*)sB, B);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL((dict_mask_atom_kernel<T>), dim3((unsigned)K), dim3(256), 0, st, (const T*)A3,
+                       (const T*)B, D, (long)F, (int)K, Dnew);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    const int mb = grid_for((long)K * F, 256);
+    hipLaunchKernelGGL((maxabsdiff_partial_kernel<T>), dim3(mb), dim3(256), 0, st, D, (const T*)Dnew,
+                       (long)K * F, dw.partial);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    hipLaunchKernelGGL((final_max_kernel<R>), dim3(1), dim3(256), 0, st, (const R*)dw.partial, (long)mb,
+                       dw.scal);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    void* hostv = nullptr;
+    DCP_TRY(host_scratch(h, 64, &hostv));
+    DCP_HIP_OK(h, hipMemcpyAsync(hostv, dw.scal, sizeof(R), hipMemcpyDeviceToHost, st));
+    DCP_HIP_OK(h, hipStreamSynchronize(st));
+    *maxdiff_host = (double)(*reinterpret_cast<R*>(hostv));
+    return DCP_OK;
+}
+
 template <class T>
 inline int gather_rows_api(dcp_handle* h, const T* in, const long long* index, int64_t rows, int64_t cols,
                            T* out) {

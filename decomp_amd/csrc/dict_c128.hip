@@ -29,4 +29,13 @@ int dcp_gather_rows_c128(dcp_handle* h, const void* in, const int64_t* index, in
                                     reinterpret_cast<dcp::c128*>(out));
 }
 
+int dcp_dict_mask_step_c128(dcp_handle* h, const void* Y, const double* mask, void* X, const void* D,
+                            void* D_new, void* A3, void* B, int64_t Nb, int64_t F, int64_t K, double beta,
+                            double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                            double* maxdiff, int* lasso_it) {
+    return dcp::dict_mask_step_api<dcp::c128>(h, reinterpret_cast<const dcp::c128*>(Y), mask, reinterpret_cast<dcp::c128*>(X), reinterpret_cast<const dcp::c128*>(D), reinterpret_cast<dcp::c128*>(D_new), reinterpret_cast<dcp::c128*>(A3), reinterpret_cast<dcp::c128*>(B), Nb, F,
+                                       K, beta, alpha, lasso_method, lasso_iter, lasso_tol, maxdiff,
+                                       lasso_it);
+}
+
 }  // extern "C"

@@ -29,4 +29,13 @@ int dcp_gather_rows_f32(dcp_handle* h, const float* in, const int64_t* index, in
                                     (out));
 }
 
+int dcp_dict_mask_step_f32(dcp_handle* h, const float* Y, const float* mask, float* X, const float* D,
+                            float* D_new, float* A3, float* B, int64_t Nb, int64_t F, int64_t K, double beta,
+                            double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                            double* maxdiff, int* lasso_it) {
+    return dcp::dict_mask_step_api<float>(h, (Y), mask, (X), (D), (D_new), (A3), (B), Nb, F,
+                                       K, beta, alpha, lasso_method, lasso_iter, lasso_tol, maxdiff,
+                                       lasso_it);
+}
+
 }  // extern "C"

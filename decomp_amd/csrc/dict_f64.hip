@@ -29,4 +29,13 @@ int dcp_gather_rows_f64(dcp_handle* h, const double* in, const int64_t* index, i
                                     (out));
 }
 
+int dcp_dict_mask_step_f64(dcp_handle* h, const double* Y, const double* mask, double* X, const double* D,
+                            double* D_new, double* A3, double* B, int64_t Nb, int64_t F, int64_t K, double beta,
+                            double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                            double* maxdiff, int* lasso_it) {
+    return dcp::dict_mask_step_api<double>(h, (Y), mask, (X), (D), (D_new), (A3), (B), Nb, F,
+                                       K, beta, alpha, lasso_method, lasso_iter, lasso_tol, maxdiff,
+                                       lasso_it);
+}
+
 }  // extern "C"

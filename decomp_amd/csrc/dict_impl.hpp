@@ -188,6 +188,83 @@ __global__ void __launch_bounds__(256) maxabsdiff_partial_kernel(const T* __rest
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
+// ---- masked dictionary learning (dictionary_learning.py:171-231) ----------------------------
+// A3[k, f, j] <- beta A3 + sum_n conj(x[n,k]) x[n,j] m[n,f]      (:209-213)
+// One workgroup per channel f; threads walk the (k, j) pairs.  O(F K^2 Nb): the reference's own
+// formulation of this statistic; a parity path, not a tuned one.
+template <class T>
+__global__ void __launch_bounds__(256) dict_mask_gram_kernel(const T* __restrict__ X,
+                                                             const real_t<T>* __restrict__ M, long Nb,
+                                                             long F, int K, real_t<T> beta,
+                                                             T* __restrict__ A3) {
+    const long f = blockIdx.x;
+    for (int e = threadIdx.x; e < K * K; e += 256) {
+        const int k = e / K, j = e % K;
+        T acc = zero_of<T>();
+        for (long n = 0; n < Nb; ++n)
+            acc = madd(acc, conj_of(X[n * K + k]), scale(X[n * K + j], M[n * F + f]));
+        T* dst = A3 + ((long)k * F + f) * K + j;
+        *dst = add(scale(*dst, beta), acc);
+    }
+}
+
+// out = beta * out + in
+template <class T>
+__global__ void __launch_bounds__(256) scale_add_kernel(long n, real_t<T> beta, const T* __restrict__ in,
+                                                        T* __restrict__ out) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
+        out[i] = add(scale(out[i], beta), in[i]);
+}
+
+// One workgroup per atom k (they are independent: the contraction uses the OLD dictionary,
+// dictionary_learning.py:219-223):  AkD_f = sum_j A3[k,f,j] D[j,f] ;  Akk = sum_f (A3[k,f,k] + eps) ;
+// u = (B_k - AkD) / Akk + D_k ;  D_new[k] = u / sqrt(max(|u|^2, 1)).
+template <class T>
+__global__ void __launch_bounds__(256) dict_mask_atom_kernel(const T* __restrict__ A3,
+                                                             const T* __restrict__ B,
+                                                             const T* __restrict__ D, long F, int K,
+                                                             T* __restrict__ Dnew) {
+    typedef real_t<T> R;
+    __shared__ R sh_re[4], sh_im[4];
+    __shared__ T s_akk;
+    __shared__ R s_nrm;
+    const int k = blockIdx.x;
+    R are = 0, aim = 0;
+    for (long f = threadIdx.x; f < F; f += 256) {
+        const T v = add(A3[((long)k * F + f) * K + k], from_real<T>(R(1.0e-15)));
+        are += real_part(v);
+        if constexpr (scalar_traits<T>::is_complex) aim += v.im;
+    }
+    const R tre = block_sum_256(are, sh_re);
+    R tim = 0;
+    if constexpr (scalar_traits<T>::is_complex) tim = block_sum_256(aim, sh_im);
+    if (threadIdx.x == 0) {
+        if constexpr (scalar_traits<T>::is_complex) { s_akk.re = tre; s_akk.im = tim; }
+        else s_akk = tre;
+    }
+    __syncthreads();
+    const T akk = s_akk;
+    R part = 0;
+    for (long f = threadIdx.x; f < F; f += 256) {
+        T dot = zero_of<T>();
+        const T* a = A3 + ((long)k * F + f) * K;
+        for (int j = 0; j < K; ++j) dot = madd(dot, a[j], D[(long)j * F + f]);
+        const T u = add(div_scalar(sub(B[(long)k * F + f], dot), akk), D[(long)k * F + f]);
+        Dnew[(long)k * F + f] = u;
+        part += abs2(u);
+    }
+    const R tot = block_sum_256(part, sh_re);
+    if (threadIdx.x == 0) s_nrm = sqrt(tot > R(1) ? tot : R(1));
+    __syncthreads();
+    const R nrm = s_nrm;
+    for (long f = threadIdx.x; f < F; f += 256) {
+        T u = Dnew[(long)k * F + f];
+        if constexpr (scalar_traits<T>::is_complex) { u.re = u.re / nrm; u.im = u.im / nrm; }
+        else u = u / nrm;
+        Dnew[(long)k * F + f] = u;
+    }
+}
+
 template <class T>
 struct DictWs {
     typedef real_t<T> R;

@@ -9,8 +9,9 @@ minibatch composition is identical); each minibatch step -- LASSO inner solve, t
 A / B statistics, the sequential atom sweep and max|D - D_new| -- is one call into
 libdecomp_hip.so (``dcp_dict_step_*``, decomp_amd/csrc/dict_impl.hpp).
 
-Not on the GPU path yet: ``mask`` (solve_cd_mask, dictionary_learning.py:171-231; SURVEY 8f
-rank 2) raises NotImplementedError.
+``mask`` selects the masked variant (solve_cd_mask, dictionary_learning.py:171-231): same
+structure with a per-channel [K, F, K] Gram statistic (``dcp_dict_mask_step_*``; a parity
+path, single GPU, memory K*F*K elements as in the reference).
 """
 import ctypes
 
@@ -53,9 +54,6 @@ def solve(y, D, alpha, x=None, tol=1.0e-3,
     get_array_module(y, D, x_given, mask)                                # :78
     if method != 'block_cd':                                             # :109-111
         raise NotImplementedError('Method %s is not yet implemented' % method)
-    if mask is not None:
-        raise NotImplementedError('dictionary_learning.solve(mask=...) (solve_cd_mask) is not '
-                                  'implemented in decomp_amd yet.')
     base = lasso_method[:-4] if lasso_method.endswith('_pos') else lasso_method
     if base not in lasso._METHOD_CODE:
         raise NotImplementedError('lasso_method %s is not implemented on the GPU path'
@@ -74,8 +72,17 @@ def solve(y, D, alpha, x=None, tol=1.0e-3,
     ybat = MinibatchData(yd, minibatch)                                  # :79-80
     xbat = MinibatchData(xd, minibatch)
     rng = np.random.RandomState(random_seed)                             # :85
-    it, Dout, xout = solve_cd(ybat, Dd, alpha, xbat, tol, minibatch, maxiter,
-                              lasso_method, lasso_iter, lasso_tol, rng, kind)
+    if mask is None:
+        it, Dout, xout = solve_cd(ybat, Dd, alpha, xbat, tol, minibatch, maxiter,
+                                  lasso_method, lasso_iter, lasso_tol, rng, kind)
+    else:
+        md = _arrays.to_device(mask, dev)
+        rdt = torch.float32 if Dd.dtype in (torch.float32, torch.complex64) else torch.float64
+        if md.dtype != rdt:
+            md = md.to(rdt)
+        mbat = MinibatchData(md.contiguous(), minibatch)
+        it, Dout, xout = solve_cd_mask(ybat, Dd, alpha, xbat, tol, minibatch, maxiter,
+                                       lasso_method, lasso_iter, lasso_tol, rng, kind, mbat)
     return it, _arrays.to_caller(Dout, kind), _arrays.to_caller(xout, kind)
 
 
@@ -117,5 +124,47 @@ def solve_cd(y, D, alpha, x, tol, minibatch, maxiter,
                 D, D_new = D_new, D
                 count += 1
         except KeyboardInterrupt:                                        # :166-167
+            return it, D, x.array
+    return maxiter, D, x.array
+
+
+def solve_cd_mask(y, D, alpha, x, tol, minibatch, maxiter,
+                  lasso_method, lasso_iter, lasso_tol, rng, xp, mask):
+    """dictionary_learning.py:171-231 with device arrays (mask: MinibatchData)."""
+    import torch
+    K, F = D.shape
+    sfx = _arrays.suffix(D)
+    lib, h = _arrays.lib_handle(D)
+    step = getattr(lib, 'dcp_dict_mask_step_' + sfx)
+    code = lasso._METHOD_CODE[lasso_method]
+    index = np.arange(y.size)
+    A = torch.zeros((K, F, K), dtype=D.dtype, device=D.device)           # :179
+    B = torch.zeros((K, F), dtype=D.dtype, device=D.device)
+    _arrays.l2_normalize_(D, strict=True)                                # :183
+    D_new = torch.empty_like(D)
+    maxdiff = ctypes.c_double(0.0)
+    lasso_it = ctypes.c_int(0)
+    count = 0
+    for it in range(1, maxiter):
+        rng.shuffle(index)
+        y.shuffle(index)
+        x.shuffle(index)
+        mask.shuffle(index)
+        try:
+            for y_mb, x_mb, m_mb in zip(y, x, mask):
+                theta_plus1 = count * minibatch + 1.0                    # :201-202
+                beta = (theta_plus1 - minibatch) / theta_plus1
+                lib, h = _arrays.lib_handle(D)
+                rc = step(h, _arrays.ptr(y_mb), _arrays.ptr(m_mb), _arrays.ptr(x_mb), _arrays.ptr(D),
+                          _arrays.ptr(D_new), _arrays.ptr(A), _arrays.ptr(B),
+                          y_mb.shape[0], F, K, float(beta), float(alpha), code,
+                          int(lasso_iter), float(lasso_tol), ctypes.byref(maxdiff),
+                          ctypes.byref(lasso_it))
+                _hip.check(h, rc, 'dcp_dict_mask_step_' + sfx)
+                if maxdiff.value < tol:                                  # :225-226
+                    return it, D_new, x.array
+                D, D_new = D_new, D
+                count += 1
+        except KeyboardInterrupt:
             return it, D, x.array
     return maxiter, D, x.array

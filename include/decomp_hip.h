@@ -254,6 +254,27 @@ int dcp_dict_step_c128(dcp_handle* h, const void* Y, void* X, const void* D, voi
  * index: int64 on the device. */
 int dcp_gather_rows_c128(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
                          int64_t cols, void* out);
+/* One minibatch step of the MASKED variant, decomp/dictionary_learning.py:192-225
+ * (solve_cd_mask): lasso with the 2-D mask, A3[K,F,K] <- beta A3 + x^H (x (x) m) (per-channel
+ * Gram, :209-213), B <- beta B + x^H (y o m), the atom update against the OLD dictionary
+ * (:218-223) and max|D - D_new| to the host.  A parity path (O(F K^2 Nb) statistic as in the
+ * reference), single GPU. */
+int dcp_dict_mask_step_f32(dcp_handle* h, const float* Y, const float* mask, float* X, const float* D,
+                            float* D_new, float* A3, float* B, int64_t Nb, int64_t F, int64_t K, double beta,
+                            double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                            double* maxdiff, int* lasso_it);
+int dcp_dict_mask_step_f64(dcp_handle* h, const double* Y, const double* mask, double* X, const double* D,
+                            double* D_new, double* A3, double* B, int64_t Nb, int64_t F, int64_t K, double beta,
+                            double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                            double* maxdiff, int* lasso_it);
+int dcp_dict_mask_step_c64(dcp_handle* h, const void* Y, const float* mask, void* X, const void* D,
+                            void* D_new, void* A3, void* B, int64_t Nb, int64_t F, int64_t K, double beta,
+                            double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                            double* maxdiff, int* lasso_it);
+int dcp_dict_mask_step_c128(dcp_handle* h, const void* Y, const double* mask, void* X, const void* D,
+                            void* D_new, void* A3, void* B, int64_t Nb, int64_t F, int64_t K, double beta,
+                            double alpha, int lasso_method, int lasso_iter, double lasso_tol,
+                            double* maxdiff, int* lasso_it);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ def _err(a, b):
 
 def _cases():
     g = _g()
-    return [str(c) for c in g['cases'] if '/mask/' not in str(c)]
+    return [str(c) for c in g['cases']]
 
 
 @pytest.mark.parametrize('name', _cases())
@@ -39,9 +39,13 @@ def test_golden(name):
         lm = parts[2].rstrip('0123456789')
         li = int(parts[2][len(lm):])
         epochs = int(parts[4][2:])
-        it, D, x = dl.solve(y.copy(), D0.copy(), 0.1, tol=0.0, minibatch=minibatch,
+        use_mask = parts[3] == 'mask'
+        mask = g[base + '/mask']
+        yy = y * mask if use_mask else y
+        it, D, x = dl.solve(yy.copy(), D0.copy(), 0.1, tol=0.0, minibatch=minibatch,
                             maxiter=epochs + 1, lasso_method=lm, lasso_iter=li,
-                            lasso_tol=1.0e-5, random_seed=0)
+                            lasso_tol=1.0e-5, random_seed=0,
+                            mask=mask.copy() if use_mask else None)
     assert it == int(g[name + '/it']), name
     assert D.dtype == y.dtype and x.shape == (101, 3)
     assert _err(D, g[name + '/D']) < 1e-7, (name, _err(D, g[name + '/D']))
