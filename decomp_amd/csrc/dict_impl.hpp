@@ -273,6 +273,7 @@ struct DictWs {
     R* partial = nullptr;   // max|dD| partials
     R* scal = nullptr;
     T* Rblk = nullptr;      // [64, F] residual rows of the atom super block being processed
+    float* ext = nullptr;   // complex64: real extended image of D_new (4KF floats)
 };
 
 template <class T>
@@ -322,6 +323,7 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
             a.A = A + (long)k0 * K; a.lda = K; a.B = Dnew; a.ldb = F;
             a.M = ns; a.N = (int)F; a.K = (int)K;
             a.tile = TILE_SMALL;
+            a.ext_ws = w.ext;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiSubFrom<T>{B + (long)k0 * F, (long)F, w.Rblk, (long)F})));
         }
         // sub-block height: the sub-block's dD rows stay within ~64 registers per thread

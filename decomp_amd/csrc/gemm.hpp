@@ -32,7 +32,58 @@ struct GemmArgs {
     bool conjA = false, conjB = false;  // complex only
     int tile = TILE_AUTO;
     bool split_planned = false;  // set by plan_splits: tile tiers may count on split-K
+    // complex64 only: scratch for the real "extended" image of B (4 * rows(B) * cols(B) floats).
+    // With it NT / NN products run on the fp32 MFMA core; TN needs none.  Null -> generic core.
+    float* ext_ws = nullptr;
 };
+
+// complex64 products on the fp32 MFMA core --------------------------------------------------
+// ext(B) for a complex [R, C] matrix: real [2R, 2C], row 2r = (re, im) pairs (B's own memory
+// image), row 2r+1 = (-im, re).  With the interleaved real view A2 of the other operand:
+//   NT, C = A B^H : C_real[m][2n], [2n+1] = A2[m, :] . ext(B)[2n], [2n+1]   (K' = 2K)
+//   NN, C = A B   : C_real[m][2n], [2n+1] = sum_kk A2[m][kk] ext(B)[kk][2n], [2n+1]
+//   TN, C = A^H B : real views of both operands, 2x2 blocks combined in the epilogue (mode 2)
+// i.e. the 4 real multiplies of every complex multiply, 8MNK flops, no operand copies except
+// the small ext(B).
+template <int TAG>   // a template only so that the header can be included in several TUs
+__global__ void __launch_bounds__(256) cplx_ext_kernel(const c64* __restrict__ B, long rows, long cols,
+                                                       long ld, float* __restrict__ out) {
+    const long n = rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const long r = i / cols, c = i - r * cols;
+        const c64 v = B[r * ld + c];
+        float* o0 = out + (2 * r) * (2 * cols) + 2 * c;
+        float* o1 = o0 + 2 * cols;
+        o0[0] = v.re; o0[1] = v.im;
+        o1[0] = -v.im; o1[1] = v.re;
+    }
+}
+
+template <class E>
+struct CplxColEpi {   // kernel epilogue mode 1
+    static constexpr int kMode = 1;
+    E e;
+    __device__ __forceinline__ void pair(int r, int c, float re, float im, int s) const {
+        e(r, c, c64{re, im}, s);
+    }
+    __device__ __forceinline__ void operator()(int, int, float, int) const {}
+};
+template <class E>
+struct CplxTnEpi {    // kernel epilogue mode 2
+    static constexpr int kMode = 2;
+    E e;
+    __device__ __forceinline__ void pair(int r, int c, float re, float im, int s) const {
+        e(r, c, c64{re, im}, s);
+    }
+    __device__ __forceinline__ void operator()(int, int, float, int) const {}
+};
+
+template <int FORM>
+inline bool cplx_on_mfma(bool conjA, bool conjB, const float* ext_ws) {
+    if (FORM == FORM_TN) return conjA && !conjB;
+    if (FORM == FORM_NT) return conjB && !conjA && ext_ws != nullptr;
+    return !conjA && !conjB && ext_ws != nullptr;
+}
 
 // MFMA tile tiers (BM, BN, BK, WM, WN, min waves/SIMD).  Measured on MI355X (tools/gemm_sweep.py,
 // Y.D^T at 65536x4096x256): 256x256 / 16 waves 139 TF, 128x128 / 4 waves 110 TF -- the big tile
@@ -82,10 +133,17 @@ template <int FORM, class T>
 inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits) {
     int bm = 64, bn = 64;
     a.split_planned = true;
-    if (std::is_same<T, float>::value) tier_dims(pick_tier<FORM>(a.M, a.N, a.K, a.tile, true), bm, bn);
-    const int n1 = a.B2 != nullptr ? a.n_b1 : a.N;
-    const long tiles = (long)ceil_div(a.M, bm) * (ceil_div(n1, bn) + ceil_div(a.N - n1, bn));
-    const long kblocks = ceil_div(a.K > 0 ? a.K : 1, 16);
+    // problem dims as the MFMA core sees them (complex64: real-extended)
+    int Mx = a.M, Nx = a.N, Kx = a.K, n1 = a.B2 != nullptr ? a.n_b1 : a.N;
+    bool mfma = std::is_same<T, float>::value;
+    if (std::is_same<T, c64>::value && cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws)) {
+        mfma = true;
+        Nx *= 2; n1 *= 2;
+        if (FORM == FORM_TN) Mx *= 2; else Kx *= 2;
+    }
+    if (mfma) tier_dims(pick_tier<FORM>(Mx, Nx, Kx, a.tile, true), bm, bn);
+    const long tiles = (long)ceil_div(Mx, bm) * (ceil_div(n1, bn) + ceil_div(Nx - n1, bn));
+    const long kblocks = ceil_div(Kx > 0 ? Kx : 1, 16);   // (real-extended depth for complex64)
     // splits allowed by the reduction depth: keep every split at least 512 deep (32 K blocks)
     // so that tile prologue / slab write-out stay small against the MFMA work
     long smax = kblocks / 32;
@@ -95,8 +153,8 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits) {
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     const long blocks_per_split = (kblocks + s - 1) / s;
-    a.klen = (int)(blocks_per_split * 16);
-    a.ksplits = ceil_div(a.K > 0 ? a.K : 1, a.klen);
+    a.klen = (int)(blocks_per_split * 16);   // in units of the core's reduction index (see gemm())
+    a.ksplits = ceil_div(Kx > 0 ? Kx : 1, a.klen);
     return a.ksplits;
 }
 
@@ -120,6 +178,48 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         }
         return launch_gemm_mfma<CfgLarge, AL, BL, Epi>(stream, p, epi);
     } else {
+        if constexpr (std::is_same<T, c64>::value) {
+            if (cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws)) {
+                GemmProblem p;
+                const float* Ar = reinterpret_cast<const float*>(a.A);
+                p.A = Ar; p.lda = 2 * a.lda;
+                p.B2 = nullptr; p.ldb2 = 0; p.n_b1 = 2 * a.N;
+                p.ksplits = a.ksplits; p.klen = a.klen;
+                p.tiles_m = p.tiles_n = 0;
+                p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
+                constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
+                constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
+                if constexpr (FORM == FORM_TN) {
+                    p.B = reinterpret_cast<const float*>(a.B); p.ldb = 2 * a.ldb;
+                    if (a.B2 != nullptr) {
+                        p.B2 = reinterpret_cast<const float*>(a.B2); p.ldb2 = 2 * a.ldb2;
+                        p.n_b1 = 2 * a.n_b1;
+                    }
+                    p.M = 2 * a.M; p.N = 2 * a.N; p.K = a.K;
+                    CplxTnEpi<Epi> ce{epi};
+                    const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
+                    if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
+                    return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
+                } else {
+                    // ext(B): [2 rows(B), 2 cols(B)] real image in the caller's scratch
+                    const long rowsB = (FORM == FORM_NT) ? a.N : a.K;
+                    const long colsB = (FORM == FORM_NT) ? a.K : a.N;
+                    long g = (rowsB * colsB + 255) / 256;
+                    if (g > 4096) g = 4096;
+                    if (g < 1) g = 1;
+                    hipLaunchKernelGGL((cplx_ext_kernel<0>), dim3((unsigned)g), dim3(256), 0, stream, a.B, rowsB,
+                                       colsB, a.ldb, a.ext_ws);
+                    p.B = a.ext_ws; p.ldb = 2 * colsB;
+                    p.M = a.M; p.N = 2 * a.N; p.K = 2 * a.K;
+                    if (a.ksplits <= 1) p.klen = 0;
+                    CplxColEpi<Epi> ce{epi};
+                    const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
+                    if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
+                    if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL>(stream, p, ce);
+                    return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
+                }
+            }
+        }
         GenericProblem<T> p;
         p.A = a.A; p.B = a.B; p.B2 = a.B2; p.n_b1 = a.n_b1;
         if (FORM == FORM_TN) { p.sAm = 1; p.sAk = a.lda; } else { p.sAm = a.lda; p.sAk = 1; }

@@ -74,6 +74,12 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return base + within;
 }
 
+// Epilogue functors may carry `static constexpr int kMode` (see the kernel's epilogue).
+template <class E, class = void>
+struct epi_mode { static constexpr int value = 0; };
+template <class E>
+struct epi_mode<E, decltype((void)E::kMode)> { static constexpr int value = E::kMode; };
+
 template <int LAY, int ROWS, int BK, int NT = 256>
 struct PanelGeom {
     static constexpr int STRIDE = (LAY == KMAJOR) ? BK : ROWS;
@@ -274,15 +280,45 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
 
     // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31,
     //      row = (r&3) + 8*(r>>2) + 4*(lane>>5) ------------------------------
+    // Epi::kMode (optional member) selects how accumulators reach the functor:
+    //   0  one real value per element                          epi(row, col, v, split)
+    //   1  complex product on real "extended" operands, output columns interleave (re, im):
+    //      lanes 2q / 2q+1 hold the two parts -> one shuffle, even lanes call the complex functor
+    //   2  complex x^H y on the real views of both operands: the 2x2 block of real sums
+    //      (rr ri; ir ii) sits in registers r, r+1 of lanes 2q, 2q+1:
+    //      re = rr + ii, im = ri - ir  (two shuffles), even lanes call the complex functor
+    constexpr int MODE = epi_mode<Epi>::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * WN + j * 32 + l31;
+            if constexpr (MODE == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (!EDGE || (row < p.M && col < ncol_end)) epi(row, col, acc[i][j][r], split);
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (!EDGE || (row < p.M && col < ncol_end)) epi(row, col, acc[i][j][r], split);
+                }
+            } else if constexpr (MODE == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = acc[i][j][r];
+                    const float o = __shfl_xor(v, 1, 64);   // executed by every lane
+                    if (!(lane & 1) && (!EDGE || (row < p.M && col < ncol_end)))
+                        epi.pair(row, col >> 1, v, o, split);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
+                    const float p1 = __shfl_xor(v1, 1, 64);
+                    const float comb = (lane & 1) ? (v0 - p1) : (v0 + p1);   // odd: ri - ir, even: rr + ii
+                    const float other = __shfl_xor(comb, 1, 64);
+                    if (!(lane & 1) && (!EDGE || (row < p.M && col < ncol_end)))
+                        epi.pair(row >> 1, col >> 1, comb, other, split);
+                }
             }
         }
     }

@@ -348,6 +348,8 @@ struct LassoWs {
     R* part = nullptr;   // column-sum partials [64, F]
     R* scal = nullptr;   // [4]: Linv, nvalid
     R* gpart = nullptr;  // [64, K] Gershgorin column-sum stripes
+    float* ext1 = nullptr;  // complex64: real extended image of a [K,F] operand (4KF floats)
+    float* ext2 = nullptr;  // complex64: real extended image of AAt (4K^2 floats)
     int* flag = nullptr;
     size_t slab_count = 0;
 };
@@ -371,6 +373,10 @@ inline void lasso_plan(WsPlan& p, int64_t N, int64_t F, int64_t K, int mask_ndim
     p.add<R>(4);
     p.add<R>((size_t)64 * K);
     p.add<int>(4);
+    if (std::is_same<T, c64>::value) {
+        p.add<float>((size_t)4 * K * F);
+        p.add<float>((size_t)4 * K * K);
+    }
 }
 
 template <class T>
@@ -397,6 +403,11 @@ inline int lasso_carve(dcp_handle* h, LassoWs<T>& w, int64_t N, int64_t F, int64
     w.scal = ws_alloc<R>(h, 4);
     w.gpart = ws_alloc<R>(h, (size_t)64 * K);
     w.flag = ws_alloc<int>(h, 4);
+    if (std::is_same<T, c64>::value) {
+        w.ext1 = ws_alloc<float>(h, (size_t)4 * K * F);
+        w.ext2 = ws_alloc<float>(h, (size_t)4 * K * K);
+        if (!w.ext1 || !w.ext2) return fail(h, DCP_ERR_INTERNAL, "lasso workspace plan mismatch");
+    }
     if (!w.An || !w.yAt || !w.AAt || !w.slabs || !w.xb[3] || !w.s || !w.alphak || !w.tolk ||
         !w.akk || !w.rowscale || !w.mbar || !w.part || !w.scal || !w.gpart || !w.flag ||
         (mask_ndim != 0 && !w.Ym) || (mask_ndim == 2 && (!w.Am || !w.T1)) ||
@@ -411,6 +422,7 @@ inline int gram_kk(dcp_handle* h, const T* P, const T* Q, int K, int F, LassoWs<
     GemmArgs<T> g;
     g.A = P; g.lda = F; g.B = Q; g.ldb = F; g.M = K; g.N = K; g.K = F;
     g.conjB = true;
+    g.ext_ws = w.ext1;
     plan_splits<FORM_NT>(g, 512, kMaxSplits);
     if ((size_t)g.ksplits * K * K > w.slab_count) return fail(h, DCP_ERR_INTERNAL, "lasso slab plan");
     DCP_LAUNCH_OK(h, (gemm<FORM_NT>(h->stream, g, EpiSlab<T>{w.slabs, K, (long)K * K})));
@@ -481,6 +493,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
     {
         GemmArgs<T> a;
         a.A = Yuse; a.lda = F; a.B = w.An; a.ldb = F; a.M = N; a.N = K; a.K = F; a.conjB = true;
+        a.ext_ws = w.ext1;
         DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a, EpiStore<T>{w.yAt, K})));
     }
     const R* rowscale = mask_ndim == 2 ? w.rowscale : nullptr;
@@ -493,6 +506,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         {   // g = yAt - x AAt
             GemmArgs<T> a;
             a.A = xcur; a.lda = K; a.B = w.AAt; a.ldb = K; a.M = N; a.N = K; a.K = K;
+            a.ext_ws = w.ext2;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiSubFrom<T>{w.yAt, K, w.G, K})));
         }
         if (K > 64 * 16) return fail(h, DCP_ERR_UNSUPPORTED, "cd: n_features > 1024 not supported");
@@ -529,6 +543,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         {   // r = y o M - (x An) o M
             GemmArgs<T> a;
             a.A = xcur; a.lda = K; a.B = w.An; a.ldb = F; a.M = N; a.N = F; a.K = K;
+            a.ext_ws = w.ext1;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiMaskedResidual<T>{w.Ym, mask, w.T1, (long)F})));
         }
         // A_k . conj(A_k) of the normalised rows, as the reference evaluates it (== 1 up to rounding)
@@ -619,14 +634,17 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             if (mask_ndim == 2) {
                 GemmArgs<T> a1;   // T1 = (V An) o M
                 a1.A = V; a1.lda = K; a1.B = w.An; a1.ldb = F; a1.M = N; a1.N = F; a1.K = K;
+                a1.ext_ws = w.ext1;
                 DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a1, EpiMulMask<T>{mask, F, w.T1, F})));
                 GemmArgs<T> a2;   // back = T1 An^H, prox step in the epilogue
                 a2.A = w.T1; a2.lda = F; a2.B = w.An; a2.ldb = F; a2.M = N; a2.N = K; a2.K = F;
                 a2.conjB = true;
+                a2.ext_ws = w.ext1;
                 DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a2, epi)));
             } else {
                 GemmArgs<T> a;    // back = V AAt, prox step in the epilogue
                 a.A = V; a.lda = K; a.B = w.AAt; a.ldb = K; a.M = N; a.N = K; a.K = K;
+                a.ext_ws = w.ext2;
                 DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, epi)));
             }
             if (check) {

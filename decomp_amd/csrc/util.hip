@@ -112,6 +112,12 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
     a.A = A; a.B = B; a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.lda = (form == FORM_TN) ? M : K;
     a.ldb = (form == FORM_NT) ? K : N;
+    if constexpr (scalar_traits<T>::is_complex) {   // the hook computes A B^H, A B, A^H B
+        a.conjB = (form == FORM_NT);
+        a.conjA = (form == FORM_TN);
+    }
+    float* ext = nullptr;
+    const size_t ext_floats = std::is_same<T, c64>::value ? (size_t)4 * N * K : 0;
     a.tile = (tile >= 3) ? TILE_LARGE : tile;   // hook-only shapes plan splits as 128x128
     hipError_t e = hipSuccess;
     if (ksplits > 1) {
@@ -121,10 +127,21 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
         a.ksplits = (int)((K + a.klen - 1) / a.klen);
         WsPlan plan;
         plan.add<T>((size_t)a.ksplits * M * N);
+        plan.add<float>(ext_floats + 4);
         DCP_TRY(ws_reserve(h, plan.total));
         ws_reset(h);
         T* slabs = ws_alloc<T>(h, (size_t)a.ksplits * M * N);
-        if (!slabs) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
+        ext = ws_alloc<float>(h, ext_floats + 4);
+        if (!slabs || !ext) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
+        if (ext_floats) {
+            a.ext_ws = ext;
+            if (form != FORM_TN) {   // the MFMA core splits the real-extended reduction (2K)
+                const long kb2 = (2 * K + 15) / 16;
+                long s2 = ksplits > kb2 ? kb2 : ksplits;
+                a.klen = (int)(((kb2 + s2 - 1) / s2) * 16);
+                a.ksplits = (int)((2 * K + a.klen - 1) / a.klen);
+            }
+        }
         EpiSlab<T> epi{slabs, (long)N, (long)M * N};
         if (form == FORM_NT) e = gemm_hook_launch<FORM_NT>(h->stream, a, tile, epi);
         else if (form == FORM_NN) e = gemm_hook_launch<FORM_NN>(h->stream, a, tile, epi);
@@ -134,6 +151,15 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
                            slabs, (long)(M * N), a.ksplits, (long)(M * N), C);
         DCP_HIP_OK(h, hipGetLastError());
     } else {
+        if (ext_floats) {
+            WsPlan plan;
+            plan.add<float>(ext_floats + 4);
+            DCP_TRY(ws_reserve(h, plan.total));
+            ws_reset(h);
+            ext = ws_alloc<float>(h, ext_floats + 4);
+            if (!ext) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
+            a.ext_ws = ext;
+        }
         EpiStore<T> epi{C, (long)N};
         if (form == FORM_NT) e = gemm_hook_launch<FORM_NT>(h->stream, a, tile, epi);
         else if (form == FORM_NN) e = gemm_hook_launch<FORM_NN>(h->stream, a, tile, epi);
@@ -264,6 +290,11 @@ int dcp_gemm_f32(dcp_handle* h, int form, const float* A, const float* B, float*
 int dcp_gemm_f64(dcp_handle* h, int form, const double* A, const double* B, double* C, int64_t M,
                  int64_t N, int64_t K, int ksplits, int tile) {
     return gemm_api<double>(h, form, A, B, C, M, N, K, ksplits, tile);
+}
+int dcp_gemm_c64(dcp_handle* h, int form, const void* A, const void* B, void* C, int64_t M, int64_t N,
+                 int64_t K, int ksplits, int tile) {
+    return gemm_api<c64>(h, form, reinterpret_cast<const c64*>(A), reinterpret_cast<const c64*>(B),
+                         reinterpret_cast<c64*>(C), M, N, K, ksplits, tile);
 }
 
 }  // extern "C"

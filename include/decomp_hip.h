@@ -97,6 +97,9 @@ int dcp_gemm_f32(dcp_handle* h, int form, const float* A, const float* B, float*
                  int64_t M, int64_t N, int64_t K, int ksplits, int tile);
 int dcp_gemm_f64(dcp_handle* h, int form, const double* A, const double* B, double* C,
                  int64_t M, int64_t N, int64_t K, int ksplits, int tile);
+/* complex64: form 0 = A B^H, 1 = A B, 2 = A^H B (the conjugations the solvers use) */
+int dcp_gemm_c64(dcp_handle* h, int form, const void* A, const void* B, void* C,
+                 int64_t M, int64_t N, int64_t K, int ksplits, int tile);
 
 /* ---- NMF, multiplicative update ------------------------------------------------ */
 /* decomp/nmf_methods/batch_mu.py:8-26 (whole loop).  D must already be l2_strict

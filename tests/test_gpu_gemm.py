@@ -88,3 +88,32 @@ def test_f64_generic(form):
             C = gemm_hip(form, A, B, ksplits=ks)
             err = np.abs(C - gemm_ref(form, A, B)) / gemm_bound(form, A, B)
             assert err.max() < 1e-14, (form, M, N, K, ks, err.max())
+
+
+def _cplx(rng, *s):
+    return (rng.randn(*s) + 1j * rng.randn(*s)).astype(np.complex64)
+
+
+@pytest.mark.parametrize('form', [0, 1, 2])
+def test_c64_on_mfma(form):
+    """complex64 products run on the fp32 MFMA core through real extended operands
+    (form 0: A B^H, 1: A B, 2: A^H B); aligned, ragged and split-K shapes."""
+    rng = np.random.RandomState(40 + form)
+    for (M, N, K, ks) in [(256, 256, 128, 1), (128, 64, 512, 4), (101, 20, 3, 1), (37, 65, 129, 3),
+                          (512, 128, 256, 1), (64, 96, 1000, 7), (5, 3, 10, 1)]:
+        if form == 0:
+            A, B = _cplx(rng, M, K), _cplx(rng, N, K)
+            ref = A.astype(np.complex128) @ B.astype(np.complex128).conj().T
+            bound = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T
+        elif form == 1:
+            A, B = _cplx(rng, M, K), _cplx(rng, K, N)
+            ref = A.astype(np.complex128) @ B.astype(np.complex128)
+            bound = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+        else:
+            A, B = _cplx(rng, K, M), _cplx(rng, K, N)
+            ref = A.astype(np.complex128).conj().T @ B.astype(np.complex128)
+            bound = np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)
+        for tile in (0, 1, 2):
+            C = gemm_hip(form, A, B, ksplits=ks, tile=tile)
+            err = np.abs(C - ref) / bound
+            assert err.max() < 2e-5, (form, M, N, K, ks, tile, err.max())
