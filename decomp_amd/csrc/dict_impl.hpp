@@ -51,19 +51,20 @@ __global__ void __launch_bounds__(256) dict_accumulate_kernel(const T* __restric
 // 2 launches per 64 atoms instead of one launch (and a K-long strided contraction) per atom.
 constexpr int kAtomSB = 64;
 
-template <class T, int BR, int CC>
-__global__ void __launch_bounds__(512) atom_super_kernel(int k0, int ns, int K, long F,
+template <class T, int BR, int CC, int NTH>
+__global__ void __launch_bounds__(NTH) atom_super_kernel(int k0, int ns, int K, long F,
                                                           const T* __restrict__ A,
                                                           T* __restrict__ Rs /* [ns, F] */,
                                                           T* __restrict__ Dnew) {
     typedef real_t<T> R_t;
     __shared__ T s_a[kAtomSB][BR + 1];   // A[k0 + r][k0 + i0 + j] for the rows r still to do
-    __shared__ R_t s_red[2][8];          // per-wave partial norms, double buffered by atom parity
+    constexpr int NW = NTH / 64;
+    __shared__ R_t s_red[2][NW];         // per-wave partial norms, double buffered by atom parity
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i0 = 0; i0 < ns; i0 += BR) {
         const int nb = min(BR, ns - i0);
         __syncthreads();
-        for (int e = tid; e < (ns - i0) * BR; e += 512) {
+        for (int e = tid; e < (ns - i0) * BR; e += NTH) {
             const int r = e / BR, j = e % BR;     // row i0 + r of the super block
             s_a[r][j] = (j < nb) ? A[(long)(k0 + i0 + r) * K + (k0 + i0 + j)] : zero_of<T>();
         }
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(512) atom_super_kernel(int k0, int ns, int K, 
         T rcur[CC], dcur[CC], rnxt[CC], dnxt[CC];
 #pragma clang loop unroll(full)
         for (int c = 0; c < CC; ++c) {
-            const long f = tid + 512L * c;
+            const long f = tid + (long)NTH * c;
             rcur[c] = (f < F) ? Rs[(long)i0 * F + f] : zero_of<T>();
             dcur[c] = (f < F) ? Dnew[(long)(k0 + i0) * F + f] : zero_of<T>();
         }
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(512) atom_super_kernel(int k0, int ns, int K, 
             if (i + 1 < nb) {
 #pragma clang loop unroll(full)
                 for (int c = 0; c < CC; ++c) {
-                    const long f = tid + 512L * c;
+                    const long f = tid + (long)NTH * c;
                     rnxt[c] = (f < F) ? Rs[(long)(i0 + i + 1) * F + f] : zero_of<T>();
                     dnxt[c] = (f < F) ? Dnew[(long)(k + 1) * F + f] : zero_of<T>();
                 }
@@ -106,21 +107,21 @@ __global__ void __launch_bounds__(512) atom_super_kernel(int k0, int ns, int K, 
                 for (int j = 0; j < BR; ++j)
                     if (j < i) acc = sub(acc, mul(s_a[i][j], dD[j][c]));
                 u[c] = add(mul(acc, rden), dcur[c]);           // dcur = D_old[k] (row k untouched)
-                const long f = tid + 512L * c;
+                const long f = tid + (long)NTH * c;
                 if (f >= F) u[c] = zero_of<T>();
                 part += abs2(u[c]);
             }
             part = wave_sum(part);
             if (lane == 0) s_red[i & 1][wave] = part;
             __syncthreads();                  // the only barrier per atom
-            R_t tot = (lane < 8) ? s_red[i & 1][lane] : R_t(0);
+            R_t tot = (lane < NW) ? s_red[i & 1][lane] : R_t(0);
 #pragma unroll
-            for (int o = 4; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            for (int o = NW / 2; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
             tot = __shfl(tot, 0, 64);         // same summation order in every wave
             const R_t rnrm = R_t(1) / sqrt(tot > R_t(1) ? tot : R_t(1));   // normalize.py:2-10 (l2)
 #pragma clang loop unroll(full)
             for (int c = 0; c < CC; ++c) {
-                const long f = tid + 512L * c;
+                const long f = tid + (long)NTH * c;
                 const T dn = scale(u[c], rnrm);
                 dD[i][c] = sub(dn, dcur[c]);
                 if (f < F) Dnew[(long)k * F + f] = dn;
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(512) atom_super_kernel(int k0, int ns, int K, 
             for (int q = 0; q < RB; ++q)
 #pragma clang loop unroll(full)
                 for (int c = 0; c < CC; ++c) {
-                    const long f = tid + 512L * c;
+                    const long f = tid + (long)NTH * c;
                     acc[q][c] = (f < F && r0 + q < ns - i0) ? Rs[(long)(i0 + r0 + q) * F + f]
                                                             : zero_of<T>();
                 }
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(512) atom_super_kernel(int k0, int ns, int K, 
             for (int q = 0; q < RB; ++q)
 #pragma clang loop unroll(full)
                 for (int c = 0; c < CC; ++c) {
-                    const long f = tid + 512L * c;
+                    const long f = tid + (long)NTH * c;
                     if (f < F && r0 + q < ns - i0) Rs[(long)(i0 + r0 + q) * F + f] = acc[q][c];
                 }
         }
@@ -314,10 +315,19 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
     DCP_LAUNCH_OK(h, hipGetLastError());
     DCP_HIP_OK(h, hipMemcpyAsync(Dnew, D, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice, st));
     // blocked atom sweep
-    const int CCneed = (int)((F + 511) / 512);
-    if (CCneed > 16) return fail(h, DCP_ERR_UNSUPPORTED, "dictionary update: n_channels > 8192");
-    for (int k0 = 0; k0 < (int)K; k0 += kAtomSB) {
-        const int ns = ((int)K - k0) < kAtomSB ? ((int)K - k0) : kAtomSB;
+    // threads per workgroup: 512 (256 registers each); 1024 for wide real dictionaries
+    // (measured at F = 8192, K = 512: f32 3.5 ms vs 6.3 ms; complex64 is faster at 512: 17 vs 28 ms)
+    const int nth = (F > 4096 && !scalar_traits<T>::is_complex) ? 1024 : 512;
+    const int CCneed = (int)((F + nth - 1) / nth);
+    if (CCneed > 16) return fail(h, DCP_ERR_UNSUPPORTED, "dictionary update: n_channels > 16384");
+    // super-block height: with many columns per thread the sub-blocks are short (register
+    // budget), so folding them into a tall super block re-streams its rows too often
+    constexpr int CXW = scalar_traits<T>::is_complex ? 2 : 1;
+    int sb = kAtomSB;
+    if (CCneed * CXW > 8) sb = 32;
+    if (CCneed * CXW > 16) sb = 16;
+    for (int k0 = 0; k0 < (int)K; k0 += sb) {
+        const int ns = ((int)K - k0) < sb ? ((int)K - k0) : sb;
         {   // R = B_blk - A[blk, :] . D_cur
             GemmArgs<T> a;
             a.A = A + (long)k0 * K; a.lda = K; a.B = Dnew; a.ldb = F;
@@ -326,23 +336,28 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
             a.ext_ws = w.ext;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiSubFrom<T>{B + (long)k0 * F, (long)F, w.Rblk, (long)F})));
         }
-        // sub-block height: the sub-block's dD rows stay within ~64 registers per thread
-#define DCP_ATOM_LAUNCH(BRV, CCV)                                                                   \
-    hipLaunchKernelGGL((atom_super_kernel<T, BRV, CCV>), dim3(1), dim3(512), 0, st, k0, ns, (int)K, \
-                       (long)F, (const T*)A, w.Rblk, Dnew)
-        // BR x CC (x2 for complex) dD registers per thread <= 64: no spills at 256 regs/thread
-        if constexpr (scalar_traits<T>::is_complex) {
-            if (CCneed <= 1) DCP_ATOM_LAUNCH(32, 1);
-            else if (CCneed <= 2) DCP_ATOM_LAUNCH(16, 2);
-            else if (CCneed <= 4) DCP_ATOM_LAUNCH(8, 4);
-            else if (CCneed <= 8) DCP_ATOM_LAUNCH(4, 8);
-            else DCP_ATOM_LAUNCH(2, 16);
-        } else {
-            if (CCneed <= 1) DCP_ATOM_LAUNCH(32, 1);
-            else if (CCneed <= 2) DCP_ATOM_LAUNCH(32, 2);
-            else if (CCneed <= 4) DCP_ATOM_LAUNCH(16, 4);
-            else if (CCneed <= 8) DCP_ATOM_LAUNCH(8, 8);
-            else DCP_ATOM_LAUNCH(4, 16);
+        // sub-block height: BR x CC (x2 for complex) dD registers per thread <= 64
+#define DCP_ATOM_LAUNCH(BRV, CCV, NTV)                                                              \
+    hipLaunchKernelGGL((atom_super_kernel<T, BRV, CCV, NTV>), dim3(1), dim3(NTV), 0, st, k0, ns,    \
+                       (int)K, (long)F, (const T*)A, w.Rblk, Dnew)
+        if (nth == 512) {
+            if constexpr (scalar_traits<T>::is_complex) {
+                if (CCneed <= 1) DCP_ATOM_LAUNCH(32, 1, 512);
+                else if (CCneed <= 2) DCP_ATOM_LAUNCH(16, 2, 512);
+                else if (CCneed <= 4) DCP_ATOM_LAUNCH(8, 4, 512);
+                else if (CCneed <= 8) DCP_ATOM_LAUNCH(4, 8, 512);
+                else DCP_ATOM_LAUNCH(2, 16, 512);
+            } else {
+                if (CCneed <= 1) DCP_ATOM_LAUNCH(32, 1, 512);
+                else if (CCneed <= 2) DCP_ATOM_LAUNCH(32, 2, 512);
+                else if (CCneed <= 4) DCP_ATOM_LAUNCH(16, 4, 512);
+                else DCP_ATOM_LAUNCH(8, 8, 512);
+            }
+        } else {   // 1024 threads: 128 registers each -> dD budget 32 (real types only)
+            if constexpr (!scalar_traits<T>::is_complex) {
+                if (CCneed <= 8) DCP_ATOM_LAUNCH(4, 8, 1024);
+                else DCP_ATOM_LAUNCH(2, 16, 1024);
+            }
         }
 #undef DCP_ATOM_LAUNCH
         DCP_LAUNCH_OK(h, hipGetLastError());

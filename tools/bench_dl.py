@@ -25,23 +25,33 @@ def main():
     ap.add_argument('--lasso', default='ista')
     ap.add_argument('--lasso-iter', type=int, default=10)
     ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--complex', action='store_true', help='complex64 (BASELINE configs[4] shape: --f 8192)')
     a = ap.parse_args()
     N, F, K, MB = a.n, a.f, a.k, a.mb
     g = torch.Generator(device='cuda')
     g.manual_seed(2)
-    Dt = torch.randn((K, F), generator=g, device='cuda')
-    xt = 30.0 * torch.randn((N, K), generator=g, device='cuda') * \
-        (torch.rand((N, K), generator=g, device='cuda') < 0.05)
-    Y = xt @ Dt + 0.1 * torch.randn((N, F), generator=g, device='cuda')
-    D = Dt + 0.2 * torch.randn((K, F), generator=g, device='cuda')
+    dt = torch.complex64 if a.complex else torch.float32
+
+    def randn(*s):
+        r = torch.randn(s, generator=g, device='cuda')
+        if a.complex:
+            return torch.complex(r, torch.randn(s, generator=g, device='cuda'))
+        return r
+    Dt = randn(K, F)
+    xt = 30.0 * randn(N, K) * (torch.rand((N, K), generator=g, device='cuda') < 0.05)
+    Y = xt @ Dt + 0.1 * randn(N, F)
+    D = Dt + 0.2 * randn(K, F)
     del xt
-    x = torch.ones((N, K), device='cuda')
+    x = torch.ones((N, K), device='cuda', dtype=dt)
     _arrays.l2_normalize_(D, strict=True)
-    A = torch.zeros((K, K), device='cuda')
-    B = torch.zeros((K, F), device='cuda')
+    A = torch.zeros((K, K), device='cuda', dtype=dt)
+    B = torch.zeros((K, F), device='cuda', dtype=dt)
     D_new = torch.empty_like(D)
-    stats = torch.empty((K, F + K), device='cuda')
+    stats = torch.empty((K, F + K), device='cuda', dtype=dt)
     md = torch.zeros((1,), device='cuda')
+    sfx = 'c64' if a.complex else 'f32'
+    fn_stats = getattr(lib_ := _hip.load(), 'dcp_dict_stats_' + sfx)
+    fn_update = getattr(lib_, 'dcp_dict_update_' + sfx)
     lib, h = _arrays.lib_handle(D)
     code = hl._METHOD_CODE[a.lasso]
     lasso_it = ctypes.c_int(0)
@@ -54,11 +64,11 @@ def main():
         beta = (theta - MB) / theta
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
-        _hip.check(h, lib.dcp_dict_stats_f32(h, _arrays.ptr(y_mb), _arrays.ptr(x_mb), _arrays.ptr(D),
+        _hip.check(h, fn_stats(h, _arrays.ptr(y_mb), _arrays.ptr(x_mb), _arrays.ptr(D),
                                              MB, F, K, 0.1, code, a.lasso_iter, 1e-5,
                                              _arrays.ptr(stats), ctypes.byref(lasso_it)), 'stats')
         ev[1].record()
-        _hip.check(h, lib.dcp_dict_update_f32(h, _arrays.ptr(stats), beta, _arrays.ptr(A),
+        _hip.check(h, fn_update(h, _arrays.ptr(stats), beta, _arrays.ptr(A),
                                               _arrays.ptr(B), _arrays.ptr(D), _arrays.ptr(D_new),
                                               F, K, _arrays.ptr(md)), 'update')
         ev[2].record()
@@ -76,10 +86,12 @@ def main():
     nnz = float((x[:MB] != 0).float().mean())
     flops = 2.0 * MB * F * K + 2.0 * K * K * F + a.lasso_iter * 2.0 * MB * K * K + \
         2.0 * MB * K * K + 2.0 * MB * K * F + 2.0 * K * K * F
-    print('dictionary step  N_mb=%d F=%d K=%d lasso=%s x%d : %.3f ms/step wall '
+    if a.complex:
+        flops *= 4.0
+    print('dictionary step %s N_mb=%d F=%d K=%d lasso=%s x%d : %.3f ms/step wall '
           '(lasso+stats %.3f ms, A/B + atom sweep + max|dD| %.3f ms)  %.1f TFLOP/s algorithmic, '
           'code density %.3f, finite D: %s'
-          % (MB, F, K, a.lasso, a.lasso_iter, wall, acc[0] / a.steps, acc[1] / a.steps,
+          % (sfx, MB, F, K, a.lasso, a.lasso_iter, wall, acc[0] / a.steps, acc[1] / a.steps,
              flops / wall / 1e9, nnz, bool(torch.isfinite(D).all())))
 
 
