@@ -121,12 +121,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # one rank per GPU; DCP_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the
+    # launch path on a 1-GPU box -- never a measurement)
+    backend = os.environ.get('DCP_DIST_BACKEND', 'nccl')
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     rows = N_ROWS // world
     if args.rows:
