@@ -169,9 +169,50 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
     return DCP_OK;
 }
 
+// PMC calibration aid (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your
+// own access pattern"): reads a [rows, cols] float matrix ONCE with exactly the global-load shape
+// of the KMAJOR panel loader (pattern 0: each wave instruction = 16 rows x 64 B, 16 floats of K per
+// step) or of the XMAJOR loader (pattern 1: 512-B contiguous row segments), summing into `out`.
+__global__ void __launch_bounds__(256) calib_read_kernel(const float* __restrict__ p, long rows,
+                                                         long cols, int pattern,
+                                                         float* __restrict__ out) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int tid = threadIdx.x;
+    if (pattern == 0) {
+        const long r0 = (long)blockIdx.x * 128;           // a 128-row panel per workgroup
+        for (long k0 = 0; k0 + 16 <= cols; k0 += 16)
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * 256;
+                const long row = r0 + idx / 4;
+                if (row < rows)
+                    acc += *reinterpret_cast<const f32x4*>(p + row * cols + k0 + (idx % 4) * 4);
+            }
+    } else {
+        const long c0 = (long)blockIdx.x * 128;           // a 128-column stripe per workgroup
+        for (long r = tid / 32; r < rows; r += 8)
+            if (c0 + (tid % 32) * 4 + 4 <= cols)
+                acc += *reinterpret_cast<const f32x4*>(p + r * cols + c0 + (tid % 32) * 4);
+    }
+    const float s = acc[0] + acc[1] + acc[2] + acc[3];
+    if (s == 12345.678f) out[0] = s;   // keeps the loads alive, (almost) never stores
+}
+
 }  // namespace
 
 extern "C" {
+
+int dcp_calib_read_f32(dcp_handle* h, const float* p, int64_t rows, int64_t cols, int pattern,
+                       float* out) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!p || !out || rows <= 0 || cols <= 0 || cols % 128 != 0)
+        return fail(h, DCP_ERR_INVALID, "bad calibration arguments");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    const unsigned grid = pattern == 0 ? (unsigned)((rows + 127) / 128) : (unsigned)(cols / 128);
+    hipLaunchKernelGGL(calib_read_kernel, dim3(grid), dim3(256), 0, h->stream, p, (long)rows, (long)cols,
+                       pattern, out);
+    DCP_HIP_OK(h, hipGetLastError());
+    return DCP_OK;
+}
 
 int dcp_create(dcp_handle** out, int device) {
     if (!out) return DCP_ERR_INVALID;

@@ -101,6 +101,13 @@ int dcp_gemm_f64(dcp_handle* h, int form, const double* A, const double* B, doub
 int dcp_gemm_c64(dcp_handle* h, int form, const void* A, const void* B, void* C,
                  int64_t M, int64_t N, int64_t K, int ksplits, int tile);
 
+/* PMC calibration aid (not a reference interface): reads p[rows, cols] exactly once with the
+ * global-load shape of the GEMM panel loaders (pattern 0: 16 rows x 64 B per wave instruction;
+ * pattern 1: 512-B row segments), so that rocprofv3 FETCH_SIZE can be compared with a known
+ * byte count (tools/calib_fetch.py). */
+int dcp_calib_read_f32(dcp_handle* h, const float* p, int64_t rows, int64_t cols, int pattern,
+                       float* out);
+
 /* ---- NMF, multiplicative update ------------------------------------------------ */
 /* decomp/nmf_methods/batch_mu.py:8-26 (whole loop).  D must already be l2_strict
  * normalised (nmf.py:70).  mask may be NULL.  On return X and D hold what the

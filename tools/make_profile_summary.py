@@ -51,7 +51,14 @@ def main():
         d = {c: sum(v) / len(v) for c, v in cs.items()}
         d['avg_us_profiled'] = sum(dur[k]) / len(dur[k])
         if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
-            d['hbm_bytes_corrected'] = (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
+            # gfx950: FETCH_SIZE under-counts wide coalesced reads by exactly 2 (guide); the
+            # K-contiguous panel loader's 64-byte row segments were calibrated separately
+            # (profiles/r01_fetch_calibration.txt): factor 1.10
+            kmajor_stream = ('gemm_mfma_kernel' in k) and (', 0, 0, ' in k or ', 0, 1, ' in k)
+            factor = 1.10 if kmajor_stream else 2.0
+            d['fetch_correction_factor'] = factor
+            d['hbm_bytes_guide_x2'] = (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
+            d['hbm_bytes_corrected'] = (factor * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
         if 'GRBM_GUI_ACTIVE' in d and 'SQ_VALU_MFMA_BUSY_CYCLES' in d:
             cyc = d['GRBM_GUI_ACTIVE'] / 8.0
             d['mfma_pipe_util'] = d['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / cyc
