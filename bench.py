@@ -49,8 +49,10 @@ def synth(n_rows, rank_seed, device):
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    summary (profiles/*_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc
-    passes, gfx950 FETCH_SIZE x2 correction).  PMC counters cannot be read inside this
+    summary (profiles/*_pmc_summary.json: (c*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc
+    passes; c = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md, 2.0 for wide
+    coalesced reads and 1.10 as calibrated for the K-contiguous panel loader's 64-byte row
+    segments, profiles/r01_fetch_calibration.txt).  PMC counters cannot be read inside this
     process, so the number is the one measured by tools/profile_round.sh on this same
     command at N = 1; None when no summary is committed."""
     import glob
