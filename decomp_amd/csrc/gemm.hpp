@@ -270,8 +270,8 @@ struct EpiMuNum {
     long ld_out;
     __device__ __forceinline__ void operator()(int r, int c, T v, int) const {
         const T d = den[(long)r * ld_den + c];
-        out[(long)r * ld_out + c] = cur[(long)r * ld_cur + c] * (v > T(0) ? v : T(0)) /
-                                    (d > T(1.0e-15) ? d : T(1.0e-15));
+        out[(long)r * ld_out + c] = cur[(long)r * ld_cur + c] * max_np(v, T(0)) /
+                                    max_np(d, T(1.0e-15));
     }
 };
 
@@ -286,8 +286,8 @@ struct EpiMuDen {
     long ld_out;
     __device__ __forceinline__ void operator()(int r, int c, T v, int) const {
         const T nu = num[(long)r * ld_num + c];
-        out[(long)r * ld_out + c] = cur[(long)r * ld_cur + c] * (nu > T(0) ? nu : T(0)) /
-                                    (v > T(1.0e-15) ? v : T(1.0e-15));
+        out[(long)r * ld_out + c] = cur[(long)r * ld_cur + c] * max_np(nu, T(0)) /
+                                    max_np(v, T(1.0e-15));
     }
 };
 

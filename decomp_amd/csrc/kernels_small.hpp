@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) mu_quotient_kernel(const T* __restrict__ 
         const T d = den_bcast == 0 ? den[r * ld_den + c] : (den_bcast == 1 ? den[r] : den[c]);
         const T nu = num[r * ld_num + c];
         out[r * ld_out + c] =
-            cur[r * ld_cur + c] * (nu > T(0) ? nu : T(0)) / (d > T(1.0e-15) ? d : T(1.0e-15));
+            cur[r * ld_cur + c] * max_np(nu, T(0)) / max_np(d, T(1.0e-15));
     }
 }
 
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) mu_quotient_slabs_kernel(const T* __restr
         for (int s = 1; s < S; ++s) nu = nu + slabs[(long)s * stride + i];
         const long r = i / cols, c = i - r * cols;
         const T d = den[r * ld_den + c];
-        out[i] = cur[i] * (nu > T(0) ? nu : T(0)) / (d > T(1.0e-15) ? d : T(1.0e-15));
+        out[i] = cur[i] * max_np(nu, T(0)) / max_np(d, T(1.0e-15));
     }
 }
 

@@ -36,7 +36,7 @@ __device__ __forceinline__ T prox_apply(T z, real_t<T> thr) {
     if constexpr (scalar_traits<T>::is_complex) {
         // lasso.py:223-225: max(|z| - t, 0) * z / (|z| + 1e-15)
         const R r = absval(z);
-        const R m = (r - thr) > R(0) ? (r - thr) : R(0);
+        const R m = max_np(r - thr, R(0));
         const R den = r + R(1.0e-15);
         T sgn;
         sgn.re = z.re / den;
@@ -45,10 +45,10 @@ __device__ __forceinline__ T prox_apply(T z, real_t<T> thr) {
     } else {
         if (PROX == PROX_POSITIVE) {  // lasso.py:241
             const T v = z - thr;
-            return v > T(0) ? v : T(0);
+            return max_np(v, T(0));
         }
         // lasso.py:206-207: max(|z| - t, 0) * sign(z)
-        const T m = (absval(z) - thr) > T(0) ? (absval(z) - thr) : T(0);
+        const T m = max_np(absval(z) - thr, T(0));
         const T sg = z > T(0) ? T(1) : (z < T(0) ? T(-1) : (z == T(0) ? T(0) : z /*NaN*/));
         return m * sg;
     }

@@ -265,13 +265,13 @@ __global__ void __launch_bounds__(256) nmf_rule_kernel(const T* __restrict__ D, 
                                                        const T* __restrict__ Q, long n, T alpha,
                                                        T* __restrict__ U) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
-        const T q = Q[i] > T(1.0e-15) ? Q[i] : T(1.0e-15);
+        const T q = max_np(Q[i], T(1.0e-15));
         T u;
         if (alpha < T(0)) {
-            u = D[i] * (P[i] > T(0) ? P[i] : T(0)) / q;
+            u = D[i] * max_np(P[i], T(0)) / q;
         } else {
             u = D[i] * ((T(1) - alpha) + alpha * P[i] / q);
-            u = u > T(0) ? u : (u == u ? T(0) : u);
+            u = max_np(u, T(0));
         }
         U[i] = u;
     }

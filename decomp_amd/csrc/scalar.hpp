@@ -78,6 +78,10 @@ DCP_HD double absval(double a) { return fabs(a); }
 DCP_HD float  absval(c64 a)  { return hypotf(a.re, a.im); }
 DCP_HD double absval(c128 a) { return hypot(a.re, a.im); }
 
+// np.maximum(a, floor): the larger value, and NaN when a is NaN (floor is a finite constant)
+DCP_HD float  max_np(float a, float floor_)   { return (a > floor_ || a != a) ? a : floor_; }
+DCP_HD double max_np(double a, double floor_) { return (a > floor_ || a != a) ? a : floor_; }
+
 DCP_HD float  real_part(float a)  { return a; }
 DCP_HD double real_part(double a) { return a; }
 template <class R> DCP_HD R real_part(cx<R> a) { return a.re; }

@@ -1,0 +1,105 @@
+"""GPU: edge cases of the three entry points -- degenerate iteration counts, single-row /
+single-atom / single-channel problems, NaN propagation, sizes that are not multiples of any
+tile -- checked against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a), np.asarray(b)
+    if np.isnan(b).any():      # a degenerate problem (0/0 in the reference too): same NaN pattern
+        return np.array_equal(np.isnan(a), np.isnan(b)) and \
+            np.allclose(a[~np.isnan(b)], b[~np.isnan(b)], rtol=tol, atol=tol)
+    return float(np.max(np.abs(a - b))) <= tol * max(1.0, float(np.max(np.abs(b))))
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (1, 7, 3), (5, 1, 2), (9, 4, 1), (131, 67, 5), (300, 129, 33)])
+@pytest.mark.parametrize('lik', ['l2', 'kl'])
+def test_nmf_odd_shapes(shape, lik):
+    import decomp_amd
+    from oracle import nmf as onmf
+    N, F, K = shape
+    rng = np.random.RandomState(N * 100 + F)
+    y = np.abs(rng.randn(N, F)) + 0.05
+    D0 = np.abs(rng.randn(K, F)) + 0.1
+    mask = np.rint(rng.uniform(0.3, 1, size=(N, F)))
+    for m in (None, mask):
+        it, D, x = decomp_amd.nmf.solve(y, D0.copy(), tol=1e-9, maxiter=15, likelihood=lik, mask=m)
+        ito, Do, xo = onmf.solve(y, D0.copy(), tol=1e-9, maxiter=15, likelihood=lik, mask=m)
+        assert it == ito
+        assert _close(D, Do, 1e-8) and _close(x, xo, 1e-8), (shape, lik, m is None)
+
+
+@pytest.mark.parametrize('maxiter', [0, 1, 2])
+def test_nmf_degenerate_maxiter(maxiter):
+    """range(1, maxiter) runs no iteration for maxiter <= 1: (maxiter, l2_strict(D), x=ones)."""
+    import decomp_amd
+    from oracle import nmf as onmf
+    rng = np.random.RandomState(0)
+    y, D0 = np.abs(rng.randn(20, 6)), np.abs(rng.randn(3, 6)) + 0.1
+    it, D, x = decomp_amd.nmf.solve(y, D0.copy(), tol=1e-3, maxiter=maxiter)
+    ito, Do, xo = onmf.solve(y, D0.copy(), tol=1e-3, maxiter=maxiter)
+    assert it == ito == maxiter
+    assert _close(D, Do, 1e-12) and _close(x, xo, 1e-12)
+
+
+def test_nmf_nan_never_converges():
+    """A NaN in y poisons max|dD|; `nan < tol` is False, so the loop runs to maxiter like NumPy."""
+    import decomp_amd
+    rng = np.random.RandomState(1)
+    y, D0 = np.abs(rng.randn(30, 8)), np.abs(rng.randn(2, 8)) + 0.1
+    y[3, 4] = np.nan
+    it, D, x = decomp_amd.nmf.solve(y, D0, tol=1e3, maxiter=6)
+    assert it == 6 and np.isnan(D).any()
+
+
+@pytest.mark.parametrize('method', ['ista', 'acc_ista', 'fista', 'cd'])
+@pytest.mark.parametrize('maxiter', [1, 2, 11])
+def test_lasso_small_iteration_counts(method, maxiter):
+    from decomp_amd import lasso
+    from oracle import lasso as olasso
+    rng = np.random.RandomState(3)
+    A, y = rng.randn(4, 9), rng.randn(6, 9)
+    it, x = lasso.solve(y, A, 0.05, tol=1e-12, method=method, maxiter=maxiter)
+    ito, xo = olasso.solve(y.copy(), A.copy(), 0.05, tol=1e-12, method=method, maxiter=maxiter)
+    assert it == ito
+    assert _close(x, xo, 1e-9), (method, maxiter)
+
+
+def test_lasso_single_atom_and_wide():
+    from decomp_amd import lasso
+    from oracle import lasso as olasso
+    rng = np.random.RandomState(4)
+    for (Nb, F, K) in [(3, 5, 1), (1, 300, 7), (70, 3, 65), (2, 2, 130)]:
+        A, y = rng.randn(K, F), rng.randn(Nb, F)
+        for method in ('ista', 'cd', 'fista_pos'):
+            it, x = lasso.solve(y, A, 0.01, tol=1e-10, method=method, maxiter=40)
+            ito, xo = olasso.solve(y.copy(), A.copy(), 0.01, tol=1e-10, method=method, maxiter=40)
+            assert it == ito and _close(x, xo, 1e-8), (Nb, F, K, method)
+
+
+def test_lasso_given_x_is_not_mutated_and_used():
+    from decomp_amd import lasso
+    from oracle import lasso as olasso
+    rng = np.random.RandomState(5)
+    A, y, x0 = rng.randn(4, 9), rng.randn(6, 9), rng.randn(6, 4)
+    keep = x0.copy()
+    it, x = lasso.solve(y, A, 0.05, x=x0, tol=1e-12, method='acc_ista', maxiter=7)
+    ito, xo = olasso.solve(y.copy(), A.copy(), 0.05, x=keep.copy(), tol=1e-12, method='acc_ista', maxiter=7)
+    assert np.array_equal(x0, keep) and it == ito and _close(x, xo, 1e-9)
+
+
+def test_dictionary_minibatch_equals_n_and_tail_rows():
+    """minibatch == n_samples (one block per epoch) and a minibatch that leaves tail rows
+    untouched that epoch (utils/data.py:115-121)."""
+    from decomp_amd import dictionary_learning as dl
+    from oracle import dictionary_learning as odl
+    rng = np.random.RandomState(6)
+    y, D0 = rng.randn(37, 6), rng.randn(4, 6)
+    for mb in (37, 10):
+        kw = dict(tol=0.0, minibatch=mb, maxiter=3, lasso_method='ista', lasso_iter=5, random_seed=2)
+        it, D, x = dl.solve(y.copy(), D0.copy(), 0.05, **kw)
+        ito, Do, xo = odl.solve(y.copy(), D0.copy(), 0.05, **kw)
+        assert it == ito and _close(D, Do, 1e-8) and _close(x, xo, 1e-8), mb
