@@ -11,8 +11,7 @@ inline void dict_plan_extra(WsPlan& p, int64_t Nb, int64_t F, int64_t K) {
     p.add<T>(dict_slab_elems<T>(Nb, F, K));
     p.add<R>((size_t)2 * ((F + 63) / 64) + 512);
     p.add<R>(4);
-    p.add<T>((size_t)64 * F);
-    if (std::is_same<T, c64>::value) p.add<float>((size_t)4 * K * F);
+    atom_plan<T>(p, F, K);
 }
 template <class T>
 inline int dict_carve_extra(dcp_handle* h, DictWs<T>& w, int64_t Nb, int64_t F, int64_t K) {
@@ -21,13 +20,8 @@ inline int dict_carve_extra(dcp_handle* h, DictWs<T>& w, int64_t Nb, int64_t F, 
     w.slabs = ws_alloc<T>(h, w.slab_count);
     w.partial = ws_alloc<R>(h, (size_t)2 * ((F + 63) / 64) + 512);
     w.scal = ws_alloc<R>(h, 4);
-    w.Rblk = ws_alloc<T>(h, (size_t)64 * F);
-    if (std::is_same<T, c64>::value) {
-        w.ext = ws_alloc<float>(h, (size_t)4 * K * F);
-        if (!w.ext) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
-    }
-    if (!w.slabs || !w.partial || !w.scal || !w.Rblk)
-        return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
+    DCP_TRY(atom_carve<T>(h, w.atom, F, K));
+    if (!w.slabs || !w.partial || !w.scal) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
     return DCP_OK;
 }
 
@@ -91,18 +85,13 @@ inline int dict_update_api(dcp_handle* h, const T* stats, double beta, T* A, T* 
     DCP_HIP_OK(h, hipSetDevice(h->device));
     WsPlan plan;
     plan.add<R>((size_t)2 * ((F + 63) / 64) + 512);
-    plan.add<T>((size_t)64 * F);
-    if (std::is_same<T, c64>::value) plan.add<float>((size_t)4 * K * F);
+    atom_plan<T>(plan, F, K);
     DCP_TRY(ws_reserve(h, plan.total));
     ws_reset(h);
     DictWs<T> dw;
     dw.partial = ws_alloc<R>(h, (size_t)2 * ((F + 63) / 64) + 512);
-    dw.Rblk = ws_alloc<T>(h, (size_t)64 * F);
-    if (std::is_same<T, c64>::value) {
-        dw.ext = ws_alloc<float>(h, (size_t)4 * K * F);
-        if (!dw.ext) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
-    }
-    if (!dw.partial || !dw.Rblk) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
+    DCP_TRY(atom_carve<T>(h, dw.atom, F, K));
+    if (!dw.partial) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
     return dict_update<T>(h, stats, (R)beta, A, B, D, Dnew, F, K, maxdiff_dev, dw);
 }
 

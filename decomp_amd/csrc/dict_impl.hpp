@@ -8,8 +8,10 @@
 //
 // The statistics product x^H [y | x] is one split-K GEMM (the same [K, F+K] layout that the
 // data-parallel driver all-reduces).  The atom sweep is inherently sequential in k (every
-// atom needs the full-row norm of the previous one): see atom_block_kernel below.
+// atom needs the full-row norm of the previous one): blocked so that all F-long work is GEMMs
+// (atom_sweep.hpp).
 #pragma once
+#include "atom_sweep.hpp"
 #include "lasso_impl.hpp"
 
 namespace dcp {
@@ -35,131 +37,6 @@ __global__ void __launch_bounds__(256) dict_accumulate_kernel(const T* __restric
         const T v = stats[i];
         if (c < F) B[r * F + c] = add(scale(B[r * F + c], beta), v);
         else A[r * K + (c - F)] = add(scale(A[r * K + (c - F)], beta), v);
-    }
-}
-
-// The atom sweep (dictionary_learning.py:154-159) is sequential in k: atom k needs the
-// full-row norm of every earlier atom.  It runs in super blocks of SB = 64 atoms:
-//   (1) R = B_blk - A[blk, :] . D_cur            one MFMA GEMM per 64 atoms
-//       (D_cur: rows < k0 already new, the rest old)
-//   (2) ONE 512-thread workgroup (8 waves: 256 registers per thread) walks the 64 atoms in
-//       sub-blocks of BR: thread t owns CC columns of F and
-//       keeps dD_j = D_new[j] - D_old[j] of the sub-block's finished atoms in registers, so
-//         u_k = (R_k - sum_{j<k in sub} A_kj dD_j) / (A_kk + 1e-15) + D_old[k]
-//       needs no memory traffic and the row norm is a block reduction (no grid sync); after
-//       a sub-block its dD is folded into the R rows of the super block still to come.
-// 2 launches per 64 atoms instead of one launch (and a K-long strided contraction) per atom.
-constexpr int kAtomSB = 64;
-
-template <class T, int BR, int CC, int NTH>
-__global__ void __launch_bounds__(NTH) atom_super_kernel(int k0, int ns, int K, long F,
-                                                          const T* __restrict__ A,
-                                                          T* __restrict__ Rs /* [ns, F] */,
-                                                          T* __restrict__ Dnew) {
-    typedef real_t<T> R_t;
-    __shared__ T s_a[kAtomSB][BR + 1];   // A[k0 + r][k0 + i0 + j] for the rows r still to do
-    constexpr int NW = NTH / 64;
-    __shared__ R_t s_red[2][NW];         // per-wave partial norms, double buffered by atom parity
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i0 = 0; i0 < ns; i0 += BR) {
-        const int nb = min(BR, ns - i0);
-        __syncthreads();
-        for (int e = tid; e < (ns - i0) * BR; e += NTH) {
-            const int r = e / BR, j = e % BR;     // row i0 + r of the super block
-            s_a[r][j] = (j < nb) ? A[(long)(k0 + i0 + r) * K + (k0 + i0 + j)] : zero_of<T>();
-        }
-        __syncthreads();
-        T dD[BR][CC];   // statically indexed (loops fully unrolled): stays in registers
-        // software pipeline: the residual / old-dictionary values of atom i+1 are in flight
-        // while atom i is reduced (the barrier would otherwise expose their latency)
-        T rcur[CC], dcur[CC], rnxt[CC], dnxt[CC];
-#pragma clang loop unroll(full)
-        for (int c = 0; c < CC; ++c) {
-            const long f = tid + (long)NTH * c;
-            rcur[c] = (f < F) ? Rs[(long)i0 * F + f] : zero_of<T>();
-            dcur[c] = (f < F) ? Dnew[(long)(k0 + i0) * F + f] : zero_of<T>();
-        }
-#pragma clang loop unroll(full)
-        for (int i = 0; i < BR; ++i) {
-            if (i >= nb) {   // nb is uniform
-#pragma clang loop unroll(full)
-                for (int c = 0; c < CC; ++c) dD[i][c] = zero_of<T>();
-                continue;
-            }
-            const int k = k0 + i0 + i;
-            if (i + 1 < nb) {
-#pragma clang loop unroll(full)
-                for (int c = 0; c < CC; ++c) {
-                    const long f = tid + (long)NTH * c;
-                    rnxt[c] = (f < F) ? Rs[(long)(i0 + i + 1) * F + f] : zero_of<T>();
-                    dnxt[c] = (f < F) ? Dnew[(long)(k + 1) * F + f] : zero_of<T>();
-                }
-            }
-            T u[CC];
-            R_t part = 0;
-            // 1 / (A_kk + 1e-15) once per atom (a reciprocal-multiply instead of CC divisions:
-            // this single-workgroup kernel is VALU-issue bound; <= 1 ulp from a true division)
-            const T rden = div_scalar(from_real<T>(R_t(1)), add(s_a[i][i], from_real<T>(R_t(1.0e-15))));
-#pragma clang loop unroll(full)
-            for (int c = 0; c < CC; ++c) {
-                T acc = rcur[c];
-#pragma clang loop unroll(full)
-                for (int j = 0; j < BR; ++j)
-                    if (j < i) acc = sub(acc, mul(s_a[i][j], dD[j][c]));
-                u[c] = add(mul(acc, rden), dcur[c]);           // dcur = D_old[k] (row k untouched)
-                const long f = tid + (long)NTH * c;
-                if (f >= F) u[c] = zero_of<T>();
-                part += abs2(u[c]);
-            }
-            part = wave_sum(part);
-            if (lane == 0) s_red[i & 1][wave] = part;
-            __syncthreads();                  // the only barrier per atom
-            R_t tot = (lane < NW) ? s_red[i & 1][lane] : R_t(0);
-#pragma unroll
-            for (int o = NW / 2; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-            tot = __shfl(tot, 0, 64);         // same summation order in every wave
-            const R_t rnrm = R_t(1) / sqrt(tot > R_t(1) ? tot : R_t(1));   // normalize.py:2-10 (l2)
-#pragma clang loop unroll(full)
-            for (int c = 0; c < CC; ++c) {
-                const long f = tid + (long)NTH * c;
-                const T dn = scale(u[c], rnrm);
-                dD[i][c] = sub(dn, dcur[c]);
-                if (f < F) Dnew[(long)k * F + f] = dn;
-                rcur[c] = rnxt[c];
-                dcur[c] = dnxt[c];
-            }
-        }
-        // fold this sub-block into the residual rows still to come (own columns only);
-        // 4 rows at a time so that 4*CC loads are in flight per thread
-        constexpr int RB = 4;
-        for (int r0 = nb; r0 < ns - i0; r0 += RB) {
-            T acc[RB][CC];
-#pragma clang loop unroll(full)
-            for (int q = 0; q < RB; ++q)
-#pragma clang loop unroll(full)
-                for (int c = 0; c < CC; ++c) {
-                    const long f = tid + (long)NTH * c;
-                    acc[q][c] = (f < F && r0 + q < ns - i0) ? Rs[(long)(i0 + r0 + q) * F + f]
-                                                            : zero_of<T>();
-                }
-#pragma clang loop unroll(full)
-            for (int q = 0; q < RB; ++q) {
-                const int r = (r0 + q < ns - i0) ? (r0 + q) : r0;
-#pragma clang loop unroll(full)
-                for (int j = 0; j < BR; ++j) {
-                    const T a = s_a[r][j];
-#pragma clang loop unroll(full)
-                    for (int c = 0; c < CC; ++c) acc[q][c] = sub(acc[q][c], mul(a, dD[j][c]));
-                }
-            }
-#pragma clang loop unroll(full)
-            for (int q = 0; q < RB; ++q)
-#pragma clang loop unroll(full)
-                for (int c = 0; c < CC; ++c) {
-                    const long f = tid + (long)NTH * c;
-                    if (f < F && r0 + q < ns - i0) Rs[(long)(i0 + r0 + q) * F + f] = acc[q][c];
-                }
-        }
     }
 }
 
@@ -273,8 +150,7 @@ struct DictWs {
     size_t slab_count = 0;
     R* partial = nullptr;   // max|dD| partials
     R* scal = nullptr;
-    T* Rblk = nullptr;      // [64, F] residual rows of the atom super block being processed
-    float* ext = nullptr;   // complex64: real extended image of D_new (4KF floats)
+    AtomWs<T> atom;         // the blocked atom sweep's buffers (atom_sweep.hpp)
 };
 
 template <class T>
@@ -315,53 +191,7 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
     DCP_LAUNCH_OK(h, hipGetLastError());
     DCP_HIP_OK(h, hipMemcpyAsync(Dnew, D, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice, st));
     // blocked atom sweep
-    // threads per workgroup: 512 (256 registers each); 1024 for wide real dictionaries
-    // (measured at F = 8192, K = 512: f32 3.5 ms vs 6.3 ms; complex64 is faster at 512: 17 vs 28 ms)
-    const int nth = (F > 4096 && !scalar_traits<T>::is_complex) ? 1024 : 512;
-    const int CCneed = (int)((F + nth - 1) / nth);
-    if (CCneed > 16) return fail(h, DCP_ERR_UNSUPPORTED, "dictionary update: n_channels > 16384");
-    // super-block height: with many columns per thread the sub-blocks are short (register
-    // budget), so folding them into a tall super block re-streams its rows too often
-    constexpr int CXW = scalar_traits<T>::is_complex ? 2 : 1;
-    int sb = kAtomSB;
-    if (CCneed * CXW > 8) sb = 32;
-    if (CCneed * CXW > 16) sb = 16;
-    for (int k0 = 0; k0 < (int)K; k0 += sb) {
-        const int ns = ((int)K - k0) < sb ? ((int)K - k0) : sb;
-        {   // R = B_blk - A[blk, :] . D_cur
-            GemmArgs<T> a;
-            a.A = A + (long)k0 * K; a.lda = K; a.B = Dnew; a.ldb = F;
-            a.M = ns; a.N = (int)F; a.K = (int)K;
-            a.tile = TILE_SMALL;
-            a.ext_ws = w.ext;
-            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiSubFrom<T>{B + (long)k0 * F, (long)F, w.Rblk, (long)F})));
-        }
-        // sub-block height: BR x CC (x2 for complex) dD registers per thread <= 64
-#define DCP_ATOM_LAUNCH(BRV, CCV, NTV)                                                              \
-    hipLaunchKernelGGL((atom_super_kernel<T, BRV, CCV, NTV>), dim3(1), dim3(NTV), 0, st, k0, ns,    \
-                       (int)K, (long)F, (const T*)A, w.Rblk, Dnew)
-        if (nth == 512) {
-            if constexpr (scalar_traits<T>::is_complex) {
-                if (CCneed <= 1) DCP_ATOM_LAUNCH(32, 1, 512);
-                else if (CCneed <= 2) DCP_ATOM_LAUNCH(16, 2, 512);
-                else if (CCneed <= 4) DCP_ATOM_LAUNCH(8, 4, 512);
-                else if (CCneed <= 8) DCP_ATOM_LAUNCH(4, 8, 512);
-                else DCP_ATOM_LAUNCH(2, 16, 512);
-            } else {
-                if (CCneed <= 1) DCP_ATOM_LAUNCH(32, 1, 512);
-                else if (CCneed <= 2) DCP_ATOM_LAUNCH(32, 2, 512);
-                else if (CCneed <= 4) DCP_ATOM_LAUNCH(16, 4, 512);
-                else DCP_ATOM_LAUNCH(8, 8, 512);
-            }
-        } else {   // 1024 threads: 128 registers each -> dD budget 32 (real types only)
-            if constexpr (!scalar_traits<T>::is_complex) {
-                if (CCneed <= 8) DCP_ATOM_LAUNCH(4, 8, 1024);
-                else DCP_ATOM_LAUNCH(2, 16, 1024);
-            }
-        }
-#undef DCP_ATOM_LAUNCH
-        DCP_LAUNCH_OK(h, hipGetLastError());
-    }
+    DCP_TRY(atom_sweep<T>(h, A, B, Dnew, F, K, w.atom));
     const int mb = grid_for((long)K * F, 256);
     hipLaunchKernelGGL((maxabsdiff_partial_kernel<T>), dim3(mb), dim3(256), 0, st, D, (const T*)Dnew,
                        (long)K * F, w.partial);
