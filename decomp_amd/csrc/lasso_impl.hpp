@@ -195,8 +195,16 @@ __global__ void __launch_bounds__(256) vec_sum_kernel(const R* __restrict__ v, l
     if (threadIdx.x == 0) out[0] = t;
 }
 
-// Coordinate-descent sweeps in Gram form.  One wave per row; lane l holds columns l + 64m.
-// Sweeps [sweep0, sweep0 + nsweeps); the LAST one is a check sweep when check_last != 0.
+// Coordinate-descent sweeps in Gram form.  One wave per row; lane l holds columns l + 64m of the
+// row's x and g in registers, plus AAt_kk, alpha_k, tol_k of its columns.
+//
+// A coordinate whose update is a zero step (x_k unchanged) leaves g untouched, so it commutes
+// with everything: per 64-column slot ALL lanes evaluate their candidate step at once, a ballot
+// finds the first coordinate (in sweep order) that really moves, only that one is applied
+// (g -= dx AAt[k, :], one coalesced row read) and the lanes behind it are re-evaluated.  The
+// sequence of applied updates is exactly that of the sequential sweep (lasso.py:539-548); with
+// sparse codes a sweep costs ~(#changed coordinates) steps instead of K.
+// Sweeps [.., + nsweeps); the LAST one is a check sweep when check_last != 0.
 template <class T, int PROX, int MAXM>
 __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __restrict__ G,
                                                       const T* __restrict__ AAt,
@@ -209,12 +217,17 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int M = (K + 63) / 64;
-    T x[MAXM], g[MAXM];
+    T x[MAXM], g[MAXM], akk[MAXM];
+    R al[MAXM], tl[MAXM];
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) {
         const int c = lane + 64 * m;
-        x[m] = (m < M && c < K) ? X[row * K + c] : zero_of<T>();
-        g[m] = (m < M && c < K) ? G[row * K + c] : zero_of<T>();
+        const bool ok = (m < M && c < K);
+        x[m] = ok ? X[row * K + c] : zero_of<T>();
+        g[m] = ok ? G[row * K + c] : zero_of<T>();
+        akk[m] = ok ? AAt[(long)c * K + c] : zero_of<T>();
+        al[m] = ok ? alphak[c] : R(0);
+        tl[m] = ok ? tolk[c] : R(1);
     }
     bool viol = false;
     for (int s = 0; s < nsweeps; ++s) {
@@ -223,30 +236,39 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
         for (int m = 0; m < MAXM; ++m) {
             if (m >= M) break;
             const int kend = min(64, K - 64 * m);
-            for (int kk = 0; kk < kend; ++kk) {
-                const int k = 64 * m + kk;
-                T gk, xk;
+            int cursor = 0;   // lanes < cursor of this slot are final for this sweep
+            while (true) {
+                // candidate step of every lane's coordinate against the current g
+                const T z = add(g[m], mul(x[m], akk[m]));
+                const T xn = prox_apply<PROX>(z, al[m]);
+                const T d = sub(xn, x[m]);
+                const bool moves = (lane >= cursor) && (lane < kend) && (abs2(d) != R(0));
+                const unsigned long long mask = __ballot(moves);
+                if (mask == 0ull) {
+                    // every remaining coordinate of the slot is a zero step: |0| - tol_k
+                    if (check && lane >= cursor && lane < kend && !((R(0) - tl[m]) < R(0))) viol = true;
+                    break;
+                }
+                const int kk = __ffsll((long long)mask) - 1;     // first moving coordinate
+                if (check && lane >= cursor && lane < kk && !((R(0) - tl[m]) < R(0))) viol = true;
+                T dk;
                 if constexpr (scalar_traits<T>::is_complex) {
-                    gk.re = __shfl(g[m].re, kk, 64); gk.im = __shfl(g[m].im, kk, 64);
-                    xk.re = __shfl(x[m].re, kk, 64); xk.im = __shfl(x[m].im, kk, 64);
+                    dk.re = __shfl(d.re, kk, 64);
+                    dk.im = __shfl(d.im, kk, 64);
                 } else {
-                    gk = __shfl(g[m], kk, 64);
-                    xk = __shfl(x[m], kk, 64);
+                    dk = __shfl(d, kk, 64);
                 }
-                const T akk = AAt[(long)k * K + k];
-                const T z = add(gk, mul(xk, akk));
-                const T xn = prox_apply<PROX>(z, alphak[k]);
-                const T d = sub(xn, xk);
-                if (check && !((absval(d) - tolk[k]) < R(0))) viol = true;
-                if (lane == kk) x[m] = xn;
-                if (abs2(d) != R(0)) {   // wave-uniform: a zero step leaves g unchanged
-                    const T* arow = AAt + (long)k * K;
+                if (lane == kk) {
+                    x[m] = xn;
+                    if (check && !((absval(d) - tl[m]) < R(0))) viol = true;
+                }
+                const T* arow = AAt + (long)(64 * m + kk) * K;
 #pragma unroll
-                    for (int mm = 0; mm < MAXM; ++mm) {
-                        const int c = lane + 64 * mm;
-                        if (mm < M && c < K) g[mm] = sub(g[mm], mul(d, arow[c]));
-                    }
+                for (int mm = 0; mm < MAXM; ++mm) {
+                    const int c = lane + 64 * mm;
+                    if (mm < M && c < K) g[mm] = sub(g[mm], mul(dk, arow[c]));
                 }
+                cursor = kk + 1;
             }
         }
     }
@@ -258,7 +280,7 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
             G[row * K + c] = g[m];
         }
     }
-    if (viol && lane == 0) *flag = 1;
+    if (__ballot(viol) != 0ull && lane == 0) *flag = 1;
 }
 
 // Masked coordinate descent, as written in lasso.py:555-583: with r = (y - x.A) o M kept in
