@@ -133,3 +133,119 @@ def nmf_solve_sharded(y_local, D, x_local=None, tol=1.0e-3, maxiter=1000, likeli
     it, Dout = mu_loop(backend, Dd, tol, maxiter, group=group, world_size=world,
                        new_like=torch.empty_like)
     return it, Dout, backend.x
+
+
+# ======================================================================================
+# Online dictionary learning, minibatch rows split over the ranks
+# ======================================================================================
+class HipDictBackend(object):
+    """The two halves of one dictionary-learning minibatch step on this rank's GPU."""
+
+    def __init__(self, D, lasso_method, lasso_iter, lasso_tol, alpha):
+        import torch
+        from . import lasso
+        self.torch = torch
+        self.sfx = _arrays.suffix(D)
+        self.K, self.F = D.shape
+        self.code = lasso._METHOD_CODE[lasso_method]
+        self.lasso_iter, self.lasso_tol, self.alpha = int(lasso_iter), float(lasso_tol), float(alpha)
+        self.stats = torch.empty((self.K, self.F + self.K), dtype=D.dtype, device=D.device)
+        rdt = torch.float32 if D.dtype in (torch.float32, torch.complex64) else torch.float64
+        self.md = torch.zeros((1,), dtype=rdt, device=D.device)
+        self.lasso_it = ctypes.c_int(0)
+
+    def local_stats(self, y_rows, x_rows, D):
+        """x_rows <- lasso(y_rows, D) in place; returns this rank's x^H [y | x]."""
+        lib, h = _arrays.lib_handle(D)
+        fn = getattr(lib, 'dcp_dict_stats_' + self.sfx)
+        _hip.check(h, fn(h, _arrays.ptr(y_rows), _arrays.ptr(x_rows), _arrays.ptr(D), y_rows.shape[0],
+                         self.F, self.K, self.alpha, self.code, self.lasso_iter, self.lasso_tol,
+                         _arrays.ptr(self.stats), ctypes.byref(self.lasso_it)), 'dcp_dict_stats')
+        return self.stats
+
+    def update(self, stats, beta, A, B, D, D_new):
+        """A, B accumulation + atom sweep + max|D - D_new| (returned as a float)."""
+        lib, h = _arrays.lib_handle(D)
+        fn = getattr(lib, 'dcp_dict_update_' + self.sfx)
+        _hip.check(h, fn(h, _arrays.ptr(stats), float(beta), _arrays.ptr(A), _arrays.ptr(B), _arrays.ptr(D),
+                         _arrays.ptr(D_new), self.F, self.K, _arrays.ptr(self.md)), 'dcp_dict_update')
+        return float(self.md.item())
+
+    def zeros_like_rows(self, x_mb):
+        return self.torch.zeros_like(x_mb)
+
+
+def dict_loop(backend, ybat, xbat, D, tol, minibatch, maxiter, rng, new_like, zeros, group=None,
+              world_size=1, rank=0):
+    """dictionary_learning.py:114-168 with every minibatch's rows split over the ranks.
+
+    Every rank holds the full (identically shuffled) y and x containers and the same D; rank r
+    runs the LASSO and the x^H [y | x] product on its contiguous share of each minibatch, the
+    [K, F+K] statistics are summed with ONE all-reduce, the A/B update and the sequential atom
+    sweep run redundantly (identical input -> identical D_new and stop decision), and the
+    minibatch's updated codes are re-assembled with a second all-reduce (each rank contributes
+    its rows, zeros elsewhere: exact).  Returns (it, D, x in the original row order)."""
+    import torch.distributed as dist
+    import numpy as np
+    K, F = D.shape
+    A = zeros((K, K))
+    B = zeros((K, F))
+    D_new = new_like(D)
+    index = np.arange(ybat.size)
+    bounds = np.linspace(0, minibatch, world_size + 1).astype(np.int64)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    count = 0
+    for it in range(1, maxiter):
+        rng.shuffle(index)
+        ybat.shuffle(index)
+        xbat.shuffle(index)
+        for y_mb, x_mb in zip(ybat, xbat):
+            stats = backend.local_stats(y_mb[lo:hi], x_mb[lo:hi], D)
+            if world_size > 1:
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+                gathered = backend.zeros_like_rows(x_mb)
+                gathered[lo:hi] = x_mb[lo:hi]
+                dist.all_reduce(gathered, op=dist.ReduceOp.SUM, group=group)
+                x_mb[...] = gathered
+            theta_plus1 = count * minibatch + 1.0
+            beta = (theta_plus1 - minibatch) / theta_plus1
+            if backend.update(stats, beta, A, B, D, D_new) < tol:
+                return it, D_new, xbat.array
+            D, D_new = D_new, D
+            count += 1
+    return maxiter, D, xbat.array
+
+
+def dictionary_learning_sharded(y, D, alpha, x=None, tol=1.0e-3, minibatch=None, maxiter=1000,
+                                lasso_method='cd', lasso_iter=10, lasso_tol=1.0e-5, random_seed=None,
+                                group=None):
+    """``decomp.dictionary_learning.solve(method='block_cd')`` with the work of every minibatch
+    split over the ranks of ``group``.  Every rank passes the same full y / D / x (torch CUDA
+    tensors or NumPy) and the same ``random_seed``; all ranks return the same (it, D, x)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from . import lasso
+    from .utils.data import MinibatchData
+    if minibatch is None:
+        raise NotImplementedError('Only online methods are implemented. minibatch is required.')
+    if lasso_method not in lasso._METHOD_CODE:
+        raise NotImplementedError('lasso_method %s is not implemented on the GPU path' % lasso_method)
+    init = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if init else 1
+    rank = dist.get_rank(group) if init else 0
+    kind = _arrays.get_array_module(D)
+    yd = _arrays.to_device(y)
+    Dd = _arrays.to_device(D, copy=True)
+    if x is None:
+        xd = torch.ones((yd.shape[0], Dd.shape[0]), dtype=Dd.dtype, device=Dd.device)
+    else:
+        xd = _arrays.to_device(x, copy=True)
+    _arrays.l2_normalize_(Dd, strict=True)
+    backend = HipDictBackend(Dd, lasso_method, lasso_iter, lasso_tol, alpha)
+    rng = np.random.RandomState(random_seed)
+    it, Dout, xout = dict_loop(
+        backend, MinibatchData(yd, minibatch), MinibatchData(xd, minibatch), Dd, tol, minibatch, maxiter,
+        rng, torch.empty_like, lambda shape: torch.zeros(shape, dtype=Dd.dtype, device=Dd.device),
+        group=group, world_size=world, rank=rank)
+    return it, _arrays.to_caller(Dout, kind), _arrays.to_caller(xout, kind)

@@ -131,3 +131,64 @@ def test_errors():
         dl.solve(y, D, 0.1, minibatch=10, method='parallel_cd')
     with pytest.raises(ValueError):
         dl.solve(y, D, 0.1, minibatch=50)                    # minibatch > n_samples
+
+
+def _sharded_dl_problem():
+    rng = np.random.RandomState(21)
+    N, F, K = 240, 64, 12
+    Dt = rng.randn(K, F)
+    xt = 3.0 * rng.randn(N, K) * (rng.uniform(size=(N, K)) < 0.2)
+    y = (xt @ Dt + 0.1 * rng.randn(N, F)).astype(np.float32)
+    return y, (Dt + 0.2 * rng.randn(K, F)).astype(np.float32)
+
+
+_DL_KW = dict(tol=0.0, minibatch=48, maxiter=3, lasso_method='ista', lasso_iter=6, lasso_tol=1e-5,
+              random_seed=3)
+
+
+def test_sharded_dictionary_world1_equals_solve():
+    from decomp_amd import dictionary_learning as dl, sharded
+    y, D0 = _sharded_dl_problem()
+    a = dl.solve(y.copy(), D0.copy(), 0.02, **_DL_KW)
+    b = sharded.dictionary_learning_sharded(y.copy(), D0.copy(), 0.02, **_DL_KW)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def _dl_gloo_gpu_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from decomp_amd import sharded
+        y, D0 = _sharded_dl_problem()
+        it, D, x = sharded.dictionary_learning_sharded(y.copy(), D0.copy(), 0.02, **_DL_KW)
+        q.put((rank, it, D, x))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_dictionary_two_ranks_on_one_gpu_gloo():
+    """Minibatch rows split over two processes sharing the test box's GPU; statistics and codes
+    exchanged over gloo: must reproduce the single-process result to rounding."""
+    import os
+    import torch.multiprocessing as mp
+    from decomp_amd import dictionary_learning as dl
+    y, D0 = _sharded_dl_problem()
+    it1, D1, x1 = dl.solve(y.copy(), D0.copy(), 0.02, **_DL_KW)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_dl_gloo_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == it1
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    assert _err(res[0][2], D1) < 1e-4 and _err(res[0][3], x1) < 1e-3

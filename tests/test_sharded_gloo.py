@@ -108,3 +108,107 @@ def test_two_rank_sharded_loop_equals_single_process(lik, masked):
     assert np.allclose(res[0][2], D_ref, rtol=1e-9, atol=1e-12)
     x_all = np.concatenate([r[3] for r in res], axis=0)
     assert np.allclose(x_all, x_ref, rtol=1e-8, atol=1e-12)
+
+
+# ---------------------------------------------------------------- dictionary learning -----
+class OracleDictBackend(object):
+    """Same interface as decomp_amd.sharded.HipDictBackend, arithmetic by the oracle."""
+
+    def __init__(self, lasso_method, lasso_iter, lasso_tol, alpha):
+        self.lm, self.li, self.lt, self.alpha = lasso_method, lasso_iter, lasso_tol, alpha
+
+    def local_stats(self, y_rows, x_rows, D):
+        from oracle import lasso as olasso
+        yn, xn, Dn = y_rows.numpy(), x_rows.numpy(), D.numpy()
+        if len(yn):
+            _, xs = olasso.solve_fastpath(yn, Dn, self.alpha, xn, self.lt, self.li, self.lm)
+            xn[...] = xs
+        xH = np.conj(xn.T)
+        return torch.from_numpy(np.ascontiguousarray(np.concatenate([xH @ yn, xH @ xn], axis=1)))
+
+    def update(self, stats, beta, A, B, D, D_new):
+        from oracle.dictionary_learning import atom_sweep
+        s = stats.numpy()
+        F = D.shape[1]
+        A[...] = torch.from_numpy(beta * A.numpy() + s[:, F:])
+        B[...] = torch.from_numpy(beta * B.numpy() + s[:, :F])
+        out = atom_sweep(D.numpy(), A.numpy(), B.numpy())
+        D_new.copy_(torch.from_numpy(out))
+        return float(np.max(np.abs(D.numpy() - out)))
+
+    def zeros_like_rows(self, x_mb):
+        return torch.zeros_like(x_mb)
+
+
+class _CpuBatches(object):
+    """decomp_amd.utils.data.MinibatchData semantics on CPU torch tensors (test stand-in)."""
+
+    def __init__(self, t, mb):
+        self._a, self.minibatch, self.size = t, mb, t.shape[0]
+        self.restore = np.arange(self.size)
+
+    @property
+    def n_loop(self):
+        return int(self.size / self.minibatch)
+
+    def shuffle(self, idx):
+        self._a = self._a[torch.from_numpy(idx)]
+        self.restore = self.restore[idx]
+
+    @property
+    def array(self):
+        return self._a[torch.from_numpy(self.restore.argsort())]
+
+    def __iter__(self):
+        for r in range(self.n_loop):
+            yield self._a[r * self.minibatch:(r + 1) * self.minibatch]
+
+
+def _dl_problem():
+    rng = np.random.RandomState(11)
+    Dt = rng.randn(3, 5)
+    xt = rng.randn(103, 3) * rng.uniform(size=(103, 3))
+    y = xt @ Dt + 0.1 * rng.randn(103, 5)
+    return y, Dt + 0.2 * rng.randn(3, 5)
+
+
+def _dl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from decomp_amd import sharded
+        from oracle.common import l2_strict
+        y, D0 = _dl_problem()
+        be = OracleDictBackend('ista', 8, 1e-5, 0.1)
+        D = torch.from_numpy(l2_strict(D0))
+        rng = np.random.RandomState(4)
+        it, Dout, xout = sharded.dict_loop(
+            be, _CpuBatches(torch.from_numpy(y.copy()), 25), _CpuBatches(torch.ones((103, 3), dtype=torch.float64), 25),
+            D, 0.0, 25, 4, rng, torch.empty_like, lambda shape: torch.zeros(shape, dtype=torch.float64),
+            world_size=world, rank=rank)
+        q.put((rank, it, Dout.numpy().copy(), xout.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_dictionary_learning_equals_single_process():
+    from oracle import dictionary_learning as odl
+    y, D0 = _dl_problem()
+    it_ref, D_ref, x_ref = odl.solve(y.copy(), D0.copy(), 0.1, tol=0.0, minibatch=25, maxiter=4,
+                                     lasso_method='ista', lasso_iter=8, lasso_tol=1e-5, random_seed=4)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_dl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == it_ref
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    assert np.allclose(res[0][2], D_ref, rtol=1e-9, atol=1e-12)
+    assert np.allclose(res[0][3], x_ref, rtol=1e-9, atol=1e-12)
