@@ -130,7 +130,7 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
 // Choose split-K so that the grid reaches ~target workgroups, each split a multiple
 // of 16 deep (the MFMA K block).  Returns the number of splits; sets a.klen.
 template <int FORM, class T>
-inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits) {
+inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_blocks = 32) {
     int bm = 64, bn = 64;
     a.split_planned = true;
     // problem dims as the MFMA core sees them (complex64: real-extended)
@@ -146,7 +146,7 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits) {
     const long kblocks = ceil_div(Kx > 0 ? Kx : 1, 16);   // (real-extended depth for complex64)
     // splits allowed by the reduction depth: keep every split at least 512 deep (32 K blocks)
     // so that tile prologue / slab write-out stay small against the MFMA work
-    long smax = kblocks / 32;
+    long smax = kblocks / min_blocks;
     if (smax < 1) smax = 1;
     if (smax > max_splits) smax = max_splits;
     long s = tiles > 0 ? target_wgs / tiles : 1;  // floor: stay within `target` resident slots

@@ -166,8 +166,22 @@ __global__ void __launch_bounds__(256) row_normalize_kernel(const T* __restrict_
     __shared__ R s_inv;
     const long row = blockIdx.x;
     const T* u = U + row * ld_u;
+    // rows of up to 4096 elements stay in registers between the two passes (one HBM/L2 round
+    // trip instead of two: this kernel sits on the replicated, latency-bound tail of a step)
+    constexpr int CACHE = 16;
+    const bool cached = F <= 256L * CACHE;
+    T rc[CACHE];
     R acc = 0;
-    for (long j = threadIdx.x; j < F; j += 256) acc += abs2(u[j]);
+    if (cached) {
+#pragma unroll
+        for (int q = 0; q < CACHE; ++q) {
+            const long j = threadIdx.x + 256L * q;
+            rc[q] = (j < F) ? u[j] : zero_of<T>();
+            acc += abs2(rc[q]);
+        }
+    } else {
+        for (long j = threadIdx.x; j < F; j += 256) acc += abs2(u[j]);
+    }
     R tot = block_sum_256(acc, sh);
     if (threadIdx.x == 0) {
         if (!strict) tot = tot > R(1) ? tot : R(1);
@@ -177,8 +191,7 @@ __global__ void __launch_bounds__(256) row_normalize_kernel(const T* __restrict_
     __syncthreads();
     const R nrm = s_inv;
     R md = 0;
-    for (long j = threadIdx.x; j < F; j += 256) {
-        const T v = u[j];
+    auto emit = [&](long j, T v) {
         T o;  // a true division, as the reference's U / sqrt(.)
         if constexpr (scalar_traits<T>::is_complex) {
             o.re = v.re / nrm;
@@ -191,6 +204,15 @@ __global__ void __launch_bounds__(256) row_normalize_kernel(const T* __restrict_
             md = (d > md || d != d) ? d : md;
         }
         out[row * ld_out + j] = o;
+    };
+    if (cached) {
+#pragma unroll
+        for (int q = 0; q < CACHE; ++q) {
+            const long j = threadIdx.x + 256L * q;
+            if (j < F) emit(j, rc[q]);
+        }
+    } else {
+        for (long j = threadIdx.x; j < F; j += 256) emit(j, u[j]);
     }
     if (rowmax != nullptr || gmax != nullptr) {
         R m = block_max_256(md, sh);

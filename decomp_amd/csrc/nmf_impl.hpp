@@ -79,7 +79,7 @@ inline size_t nmf_slab_elems(const NmfShape<T>& s) {
     size_t stats_slabs = (size_t)a.ksplits * s.K * W;
     GemmArgs<T> g;
     g.M = (int)s.K; g.N = (int)s.K; g.K = (int)s.F;
-    plan_splits<FORM_NT>(g, 512, kMaxSplits);
+    plan_splits<FORM_NT>(g, 512, kMaxSplits, 16);
     size_t g_slabs = (size_t)g.ksplits * s.K * s.K;
     GemmArgs<T> pg;
     const int ps = nmf_xupdate_splits<T>(s.N, s.F, s.K, pg);
@@ -193,7 +193,7 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
             ProfScope ps(h, DCP_PROF_GRAM);
             GemmArgs<T> g;
             g.A = D; g.lda = F; g.B = D; g.ldb = F; g.M = K; g.N = K; g.K = F;
-            plan_splits<FORM_NT>(g, 512, kMaxSplits);
+            plan_splits<FORM_NT>(g, 512, kMaxSplits, 16);   // tiny output: 256-deep splits (measured best)
             DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, g, EpiSlab<T>{w.slabs, K, (long)K * K})));
             hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * K)), dim3(256), 0,
                                st, w.slabs, (long)K * K, g.ksplits, (long)K * K, w.G);
