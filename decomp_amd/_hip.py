@@ -16,6 +16,7 @@ ERR_NAMES = {-1: 'DCP_ERR_INVALID', -2: 'DCP_ERR_HIP', -3: 'DCP_ERR_NOMEM',
              -4: 'DCP_ERR_INTERNAL', -5: 'DCP_ERR_UNSUPPORTED'}
 LIK_L2, LIK_KL = 0, 1
 PROF_NLABELS = 9
+PROF_XUPDATE, PROF_STATS = 2, 4
 LASSO_ISTA, LASSO_ACC_ISTA, LASSO_FISTA, LASSO_CD = 0, 1, 2, 3
 
 _c_int, _c_i64, _c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
@@ -32,6 +33,7 @@ SIGNATURES = {
     'dcp_build_info': (ctypes.c_char_p, []),
     'dcp_profile_enable': (_c_int, [_c_vp, _c_int]),
     'dcp_profile_reset': (_c_int, [_c_vp]),
+    'dcp_profile_select': (_c_int, [_c_vp, ctypes.c_uint]),
     'dcp_profile_read': (_c_int, [_c_vp, _c_int, _P(_c_f64), _P(_c_i64)]),
     'dcp_profile_label_name': (ctypes.c_char_p, [_c_int]),
     'dcp_l2_normalize_f32': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_int]),

@@ -25,6 +25,7 @@ struct dcp_handle {
     std::string err;
     // optional per-kernel timing (dcp_profile_*): hipEvent pairs around labelled launches
     bool prof_on = false;
+    unsigned prof_mask = 0xffffffffu;   // labels that are timed while prof_on
     struct ProfRec { int label; hipEvent_t a, b; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -70,7 +71,7 @@ struct ProfScope {
         return e;
     }
     ProfScope(dcp_handle* h_, int label_) : h(h_), label(label_) {
-        if (!h->prof_on) return;
+        if (!h->prof_on || !((h->prof_mask >> label) & 1u)) return;
         a = take(h);
         b = take(h);
         if (a) (void)hipEventRecord(a, h->stream);

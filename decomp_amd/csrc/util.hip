@@ -256,6 +256,12 @@ int dcp_profile_enable(dcp_handle* h, int on) {
     return DCP_OK;
 }
 
+int dcp_profile_select(dcp_handle* h, unsigned label_mask) {
+    if (!h) return DCP_ERR_INVALID;
+    h->prof_mask = label_mask;
+    return DCP_OK;
+}
+
 static int prof_fold(dcp_handle* h) {
     if (h->prof_recs.empty()) return DCP_OK;
     DCP_HIP_OK(h, hipSetDevice(h->device));

@@ -72,6 +72,9 @@ enum {
     DCP_PROF_NLABELS = 9
 };
 int dcp_profile_enable(dcp_handle* h, int on);
+/* restrict the brackets to the labels whose bit is set (each bracket costs ~4 us of stream time:
+ * bench.py times only the dominant kernel inside its timed steps) */
+int dcp_profile_select(dcp_handle* h, unsigned label_mask);
 int dcp_profile_reset(dcp_handle* h);
 int dcp_profile_read(dcp_handle* h, int label, double* total_ms, int64_t* count);
 const char* dcp_profile_label_name(int label);
