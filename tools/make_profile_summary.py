@@ -27,7 +27,7 @@ def main():
     ks = glob.glob(os.path.join(src, 'kt', '*', '*_kernel_stats.csv'))[0]
     rows = list(csv.DictReader(open(ks)))
     with open(os.path.join(out_dir, tag + '_kernel_stats.csv'), 'w') as f:
-        f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline\n')
+        f.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py   (default: --gpus 1 --steps 50 --warmup 5)\n')
         f.write('Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n')
         for r in rows:
             f.write('"%s",%s,%s,%s,%s,%s,%s\n' % (short(r['Name'])[:160], r['Calls'], r['TotalDurationNs'],
