@@ -216,3 +216,52 @@ def test_sharded_two_ranks_on_one_gpu_gloo():
     x_all = np.concatenate([res[0][3], res[1][3]], axis=0)
     if res[0][1] == it1:
         assert _rel(res[0][2], D1) < 1e-4 and _rel(x_all, x1) < 1e-3
+
+
+def _rccl_world1_worker(port, q):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        from decomp_amd import _hip, sharded
+        y, D0, _ = _sharded_problem()
+        Y = torch.from_numpy(y).cuda()
+        D = torch.from_numpy(D0).cuda()
+        from decomp_amd import _arrays
+        _arrays.l2_normalize_(D, strict=True)
+        x = torch.ones((Y.shape[0], D.shape[0]), dtype=torch.float32, device='cuda')
+        backend = sharded.HipStepBackend(Y, None, x, D, _hip.LIK_L2)
+        # world_size=2 forces the collective call; on a 1-rank RCCL group it is the identity
+        it, Dout = sharded.mu_loop(backend, D, 2e-3, 200, world_size=2, new_like=torch.empty_like)
+        torch.cuda.synchronize()
+        q.put((it, Dout.cpu().numpy(), backend.x.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_loop_over_rccl_world1():
+    """The step loop with the REAL RCCL backend ("nccl") on the one GPU of the test box: the
+    all-reduce is issued every iteration on a 1-rank communicator (identity), which exercises
+    the stream ordering between the library's kernels and the collective; result must equal
+    nmf.solve bit for bit."""
+    import os
+    import torch.multiprocessing as mp
+    import decomp_amd
+    y, D0, _ = _sharded_problem()
+    it1, D1, x1 = decomp_amd.nmf.solve(y, D0.copy(), tol=2e-3, maxiter=200)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000)
+    p = ctx.Process(target=_rccl_world1_worker, args=(port, q))
+    p.start()
+    it, D, x = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert it == it1
+    assert np.array_equal(D, D1) and np.array_equal(x, x1)
