@@ -6,6 +6,8 @@ Restates, in NumPy, the reference's
   decomp/lasso.py:244-271   one proximal-gradient step (plain and masked)
   decomp/lasso.py:274-445   ista / acc_ista / fista, plain and 2-D-masked
   decomp/lasso.py:526-583   coordinate descent, plain and masked (as written)
+  decomp/lasso.py:448-523   parallel (shotgun) coordinate descent, plain and masked
+  decomp/lasso.py:586-657   ADMM, plain and masked (+ math_utils/linalg.py:9-16 inverse)
 The three proximal-gradient solvers share one loop here (they differ only in
 the extrapolation coefficient and in which iterate is returned on exhaustion);
 the reference's quirks are kept and marked QUIRK.
@@ -18,7 +20,7 @@ agree to float32 rounding, which is the tolerance the fixtures are checked at.
 import numpy as np
 from .common import JITTER, gershgorin, real_dtype
 
-METHODS = ('ista', 'acc_ista', 'fista', 'cd')
+METHODS = ('ista', 'acc_ista', 'fista', 'cd', 'parallel_cd', 'admm')
 
 
 # ----------------------------------------------------------------- prox ----
@@ -139,6 +141,93 @@ def _cd(y, A, alpha, x, tol, maxiter, positive, mask):
     return maxiter - 1, x
 
 
+# ------------------------------------------- parallel coordinate descent ---
+def _parallel_cd(y, A, alpha, x0, tol, maxiter, positive, mask):
+    """lasso.py:448-484 (plain) and 487-523 (2-D mask).
+
+    Every iteration evaluates the full unit-step proximal update, then commits it
+    only on the p coordinates selected by a 0/1 vector that is re-shuffled by
+    RandomState(0) each iteration (cumulative shuffles of ONE vector).  p =
+    int(K / Gershgorin(AAt)); AAt is the unmasked Gram matrix in both variants.
+    """
+    shrink = _pick_shrink(A, positive)
+    At = _adjoint(A, positive)
+    rng = np.random.RandomState(0)                             # :463
+    AAt = A.dot(At)                                            # :464 / :503
+    rho = gershgorin(AAt)
+    K = A.shape[0]
+    p = int((K / rho).reshape(-1)[0])                          # :468
+    if p <= 1:
+        if mask is not None:
+            # QUIRK (:509): the masked fallback call drops `positive`, so the
+            # reference dies with a TypeError (missing argument 'xp').
+            raise TypeError("_solve_cd_mask() missing 1 required positional "
+                            "argument: 'xp'")
+        return _cd(y, A, alpha, x0, tol, maxiter, positive, None)
+    if mask is None:
+        yAt = np.tensordot(y, At, axes=1)                      # :472
+    else:
+        yAt = np.tensordot(y * mask, At, axes=1)               # :511
+    select = np.zeros(K, dtype=real_dtype(y.dtype))
+    select[:p] = 1.0                                           # :473-474
+    for i in range(maxiter):
+        if mask is None:
+            back = np.tensordot(x0, AAt, axes=1)
+        else:
+            back = np.tensordot(np.tensordot(x0, A, axes=1) * mask, At, axes=1)
+        x_new = shrink(x0 + 1.0 * (yAt - back), alpha)         # step 1, threshold alpha
+        dx = x_new - x0
+        if i % 10 == 0 and np.max(np.abs(dx) - tol) < 0.0:
+            return i, x_new
+        rng.shuffle(select)                                    # :481
+        x0 += dx * select                                      # in place
+    return maxiter - 1, x0
+
+
+# ----------------------------------------------------------------- ADMM ----
+def _admm(y, A, alpha, x, tol, maxiter, positive, mask, rho=1.0):
+    """lasso.py:586-618 (plain) and 621-657 (2-D mask: one K x K system per row).
+
+    QUIRK: `AAt + rho * eye(K)` adds a float64 identity, so a float32 / complex64
+    problem is silently promoted and iterated in double precision; the result
+    comes back as float64 / complex128.
+    """
+    shrink = _pick_shrink(A, positive)
+    At = _adjoint(A, positive)
+    K = A.shape[0]
+    if mask is None:
+        yAt = np.tensordot(y, At, axes=1)                      # :601
+        AAt = A.dot(At)
+        system_inv = np.linalg.inv(AAt + rho * np.eye(K))      # :603
+
+        def apply_inv(v):
+            return v.dot(system_inv)
+        squeeze = False
+    else:
+        yAt = np.tensordot(y * mask, At, axes=1)[..., None, :]  # :638
+        x = x[..., None, :]
+        alpha = alpha[..., None, :]
+        tol = tol[None, :]
+        AAt = np.tensordot(mask[..., None, :] * A, At, axes=1)  # :643  [..., K, K]
+        system_inv = np.linalg.inv(AAt + rho * np.eye(K))
+
+        def apply_inv(v):
+            return np.matmul(v, system_inv)
+        squeeze = True
+    thr = alpha / rho
+    u = x.copy()
+    z = x.copy()
+    for i in range(maxiter):
+        x_new = apply_inv(yAt + rho * (z - u))                 # :609
+        z = shrink(x_new + u, thr)
+        if i % 10 == 0 and (np.max(np.abs(x - x_new) - tol) < 0.0 and
+                            np.max(np.abs(z - x_new) - tol) < 0.0):
+            return i, (x_new[..., 0, :] if squeeze else x_new)
+        x = x_new
+        u = u + x - z
+    return maxiter - 1, (x[..., 0, :] if squeeze else x)
+
+
 # --------------------------------------------------------- fast path -------
 def solve_fastpath(y, A, alpha, x, tol, maxiter, method, mask=None):
     """lasso.py:97-189."""
@@ -170,6 +259,10 @@ def solve_fastpath(y, A, alpha, x, tol, maxiter, method, mask=None):
 
     if method == 'cd':
         it, x = _cd(y, A, alpha, x, tol, maxiter, positive, full_mask)
+    elif method == 'parallel_cd':
+        it, x = _parallel_cd(y, A, alpha, x, tol, maxiter, positive, full_mask)
+    elif method == 'admm':
+        it, x = _admm(y, A, alpha, x, tol, maxiter, positive, full_mask)
     else:
         it, x = _prox_grad(y, A, alpha, x, tol, maxiter, positive, full_mask,
                            method)

@@ -225,6 +225,92 @@ def gen_lasso(ref, out):
     print('lasso: %d cases' % len(cases))
 
 
+def lasso_inputs_wide(seed, N, K, F, kind, correlated=False):
+    """A wider problem than the reference's 5 x 10 test design, so that parallel_cd commits
+    several coordinates per iteration; `correlated` makes the atoms nearly parallel
+    (Gershgorin bound ~ K, p <= 1: the fallback branch of lasso.py:469-470)."""
+    rng = np.random.RandomState(seed)
+
+    def randn(*s):
+        if kind in ('c128', 'c64'):
+            return rng.randn(*s) + rng.randn(*s) * 1.0j
+        return rng.randn(*s)
+
+    A = randn(K, F)
+    if correlated:
+        A = randn(1, F) + 0.05 * A
+    xt = randn(N, K) * np.rint(rng.uniform(size=(N, K)))
+    y = np.dot(xt, A) + randn(N, F) * 0.1
+    mask = np.rint(rng.uniform(0.4, 1, size=(N, F)))
+    if kind == 'f32':
+        A, y, mask = A.astype(np.float32), y.astype(np.float32), mask.astype(np.float32)
+    if kind == 'c64':
+        A, y, mask = A.astype(np.complex64), y.astype(np.complex64), mask.astype(np.float32)
+    return y, A, mask
+
+
+def gen_lasso_extra(ref, out):
+    """parallel_cd and admm: lasso.py:448-523, 586-657."""
+    data = {}
+    cases = []
+
+    def run(name, y, A, m, method, tol, maxiter, alpha=0.1):
+        try:
+            it, x = ref.lasso.solve(y.copy(), A.copy(), alpha=alpha, tol=tol, method=method,
+                                    maxiter=maxiter, mask=None if m is None else m.copy())
+            data[name + '/it'] = np.int64(it)
+            data[name + '/x'] = np.asarray(x)
+            data[name + '/raises'] = np.array('')
+        except TypeError as e:      # lasso.py:509 (masked parallel_cd fallback)
+            data[name + '/it'] = np.int64(-1)
+            data[name + '/x'] = np.zeros(0)
+            data[name + '/raises'] = np.array('TypeError')
+        cases.append(name)
+        data[name + '/tol'] = np.float64(tol)
+        data[name + '/maxiter'] = np.int64(maxiter)
+        data[name + '/alpha'] = np.float64(alpha)
+
+    shapes = {'vec': (), 'mat': (11,), 'ten': (12, 11)}
+    for kind in ('f64', 'c128', 'f32'):
+        methods = ['parallel_cd', 'admm']
+        if kind != 'c128':
+            methods += ['parallel_cd_pos', 'admm_pos']
+        for sname, bshape in shapes.items():
+            y, A, mask, mask1d = lasso_inputs(0, bshape, 5, 10, kind)
+            base = 'lasso_%s_%s' % (kind, sname)       # same inputs as lasso_golden.npz
+            data[base + '/y'] = y
+            data[base + '/A'] = A
+            data[base + '/mask2d'] = mask
+            data[base + '/mask1d'] = mask1d
+            for mname, m in (('nomask', None), ('mask1d', mask1d), ('mask2d', mask)):
+                if m is not None and m.ndim > 1 and y.ndim == 1:
+                    pass
+                for method in methods:
+                    for (tol, maxiter, tag) in ((1.0e-6, 1000, 'conv'), (1.0e-9, 7, 'exh')):
+                        if kind == 'f32' and tag == 'conv':
+                            tol = 1.0e-5
+                        run('%s/%s/%s/%s' % (base, mname, method, tag), y, A, m, method, tol,
+                            maxiter)
+    for kind in ('f64', 'f32', 'c128', 'c64'):
+        for tag, corr in (('wide', False), ('corr', True)):
+            y, A, mask = lasso_inputs_wide(3, 16, 24, 64, kind, correlated=corr)
+            base = 'lasso_%s_%s' % (kind, tag)
+            data[base + '/y'] = y
+            data[base + '/A'] = A
+            data[base + '/mask2d'] = mask
+            methods = ['parallel_cd', 'admm'] if tag == 'wide' else ['parallel_cd']
+            if kind[0] == 'f':
+                methods = methods + [m + '_pos' for m in methods]
+            for mname, m in (('nomask', None), ('mask2d', mask)):
+                for method in methods:
+                    tol = 1.0e-5 if kind in ('f32', 'c64') else 1.0e-7
+                    run('%s/%s/%s/conv' % (base, mname, method), y, A, m, method, tol, 400)
+                    run('%s/%s/%s/exh' % (base, mname, method), y, A, m, method, 1.0e-12, 13)
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(out, 'lasso_extra_golden.npz'), **data)
+    print('lasso extra: %d cases' % len(cases))
+
+
 # ------------------------------------------------- dictionary learning -----
 def dl_inputs(seed, complex_):
     """Generator of tests/test_dictionary.py:35-43."""
@@ -303,6 +389,7 @@ def main():
     gen_nmf(ref, args.out)
     gen_nmf_minibatch(ref, args.out)
     gen_lasso(ref, args.out)
+    gen_lasso_extra(ref, args.out)
     gen_dl(ref, args.out)
     return 0
 

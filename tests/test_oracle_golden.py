@@ -123,6 +123,34 @@ def test_lasso_all_cases(golden_dir):
         assert x.shape == xr.shape
 
 
+def test_lasso_parallel_cd_and_admm_cases(golden_dir):
+    """lasso.py:448-523 and 586-657: the oracle performs the same
+    operations on the same dtypes as the reference (including ADMM's silent promotion to
+    double), so iteration counts and values agree to rounding for every dtype."""
+    g = _load(golden_dir, 'lasso_extra_golden.npz')
+    cases = [str(c) for c in g['cases']]
+    assert len(cases) == 252
+    n_raise = 0
+    for name in cases:
+        base, mname, method, tag = name.split('/')
+        y, A = g[base + '/y'], g[base + '/A']
+        mask = None if mname == 'nomask' else g[base + '/' + mname]
+        kw = dict(tol=float(g[name + '/tol']), method=method, maxiter=int(g[name + '/maxiter']),
+                  mask=None if mask is None else mask.copy())
+        if str(g[name + '/raises']) == 'TypeError':
+            n_raise += 1
+            with pytest.raises(TypeError):
+                olasso.solve(y.copy(), A.copy(), float(g[name + '/alpha']), **kw)
+            continue
+        it, x = olasso.solve(y.copy(), A.copy(), float(g[name + '/alpha']), **kw)
+        xr = g[name + '/x']
+        assert it == int(g[name + '/it']), name
+        assert x.dtype == xr.dtype and x.shape == xr.shape, name
+        assert _close(x, xr, 1.0e-9 if x.dtype.itemsize >= 8 and x.dtype != np.complex64
+                      else 1.0e-5), name
+    assert n_raise == 12
+
+
 # ------------------------------------------------- dictionary learning -----
 def test_dictionary_learning_all_cases(golden_dir):
     g = _load(golden_dir, 'dl_golden.npz')
