@@ -10,7 +10,7 @@ Drop-in for the reference's ``decomp.nmf.solve`` / ``decomp.lasso.solve`` /
 All arithmetic runs in hand-written HIP kernels (libdecomp_hip.so, gfx950) behind a
 plain C ABI (include/decomp_hip.h); there is no CPU fallback.
 """
-from . import nmf, lasso, dictionary_learning  # noqa: F401
+from . import nmf, lasso, nnls, dictionary_learning  # noqa: F401
 from .utils import exceptions  # noqa: F401
 
 __version__ = '0.1.0'

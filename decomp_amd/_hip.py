@@ -13,11 +13,14 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libdecomp_hip.so')
 
 OK = 0
 ERR_NAMES = {-1: 'DCP_ERR_INVALID', -2: 'DCP_ERR_HIP', -3: 'DCP_ERR_NOMEM',
-             -4: 'DCP_ERR_INTERNAL', -5: 'DCP_ERR_UNSUPPORTED'}
+             -4: 'DCP_ERR_INTERNAL', -5: 'DCP_ERR_UNSUPPORTED', -6: 'DCP_ERR_REF_TYPEERROR'}
 LIK_L2, LIK_KL = 0, 1
 PROF_NLABELS = 9
 PROF_XUPDATE, PROF_STATS = 2, 4
 LASSO_ISTA, LASSO_ACC_ISTA, LASSO_FISTA, LASSO_CD = 0, 1, 2, 3
+LASSO_PARALLEL_CD, LASSO_ADMM = 4, 5
+LASSO_POSITIVE = 0x100
+ERR_REF_TYPEERROR = -6
 
 _c_int, _c_i64, _c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
 _c_f32, _c_f64 = ctypes.c_float, ctypes.c_double
@@ -50,6 +53,14 @@ SIGNATURES = {
     'dcp_lasso_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_int, _P(_c_int)]),
     'dcp_lasso_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_int, _P(_c_int)]),
     'dcp_lasso_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_int, _P(_c_int)]),
+    'dcp_lasso_pcd_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_vp, _c_i64, _P(_c_int)]),
+    'dcp_lasso_admm_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_int)]),
+    'dcp_lasso_pcd_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_vp, _c_i64, _P(_c_int)]),
+    'dcp_lasso_admm_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_int)]),
+    'dcp_lasso_pcd_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_vp, _c_i64, _P(_c_int)]),
+    'dcp_lasso_admm_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_int)]),
+    'dcp_lasso_pcd_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_vp, _c_i64, _P(_c_int)]),
+    'dcp_lasso_admm_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_int)]),
     'dcp_dict_stats_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
     'dcp_dict_update_f32': (_c_int, [_c_vp, _c_vp, _c_f64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_step_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),

@@ -35,6 +35,32 @@ inline int dict_check(dcp_handle* h, const void* a, const void* b, const void* c
     return DCP_OK;
 }
 
+// lasso_method arrives as DCP_LASSO_* optionally OR'ed with DCP_LASSO_POSITIVE ('_pos' solvers)
+inline bool dict_lasso_method_ok(int lasso_method) {
+    const int base = lasso_method & ~DCP_LASSO_POSITIVE;
+    return base >= DCP_LASSO_ISTA && base <= DCP_LASSO_ADMM && base != DCP_LASSO_PARALLEL_CD;
+}
+
+template <class T>
+inline int dict_lasso(dcp_handle* h, const T* Y, const real_t<T>* M, int mask_ndim, const T* D, T* X,
+                      int64_t Nb, int64_t F, int64_t K, double alpha, double lasso_tol, int lasso_iter,
+                      int lasso_method, int* it, LassoWs<T>& lw) {
+    typedef real_t<T> R;
+    const int base = lasso_method & ~DCP_LASSO_POSITIVE;
+    const bool positive = (lasso_method & DCP_LASSO_POSITIVE) != 0;
+    if constexpr (scalar_traits<T>::is_complex) {
+        if (positive) return fail(h, DCP_ERR_INVALID, "positive solvers need a real dtype (lasso.py:92)");
+        return lasso_solve<T, PROX_COMPLEX>(h, Y, M, mask_ndim, D, X, Nb, F, K, (R)alpha, (R)lasso_tol,
+                                            lasso_iter, base, it, lw);
+    } else {
+        if (positive)
+            return lasso_solve<T, PROX_POSITIVE>(h, Y, M, mask_ndim, D, X, Nb, F, K, (R)alpha,
+                                                 (R)lasso_tol, lasso_iter, base, it, lw);
+        return lasso_solve<T, PROX_REAL>(h, Y, M, mask_ndim, D, X, Nb, F, K, (R)alpha, (R)lasso_tol,
+                                         lasso_iter, base, it, lw);
+    }
+}
+
 // lasso on this rank's minibatch rows + local x^H [y | x]
 template <class T>
 inline int dict_stats_core(dcp_handle* h, const T* Y, T* X, const T* D, int64_t Nb, int64_t F, int64_t K,
@@ -42,13 +68,8 @@ inline int dict_stats_core(dcp_handle* h, const T* Y, T* X, const T* D, int64_t 
                            int* lasso_it, LassoWs<T>& lw, DictWs<T>& dw) {
     typedef real_t<T> R;
     int it = 0;
-    if constexpr (scalar_traits<T>::is_complex) {
-        DCP_TRY((lasso_solve<T, PROX_COMPLEX>(h, Y, (const R*)nullptr, 0, D, X, Nb, F, K, (R)alpha,
-                                              (R)lasso_tol, lasso_iter, lasso_method, &it, lw)));
-    } else {
-        DCP_TRY((lasso_solve<T, PROX_REAL>(h, Y, (const R*)nullptr, 0, D, X, Nb, F, K, (R)alpha,
-                                           (R)lasso_tol, lasso_iter, lasso_method, &it, lw)));
-    }
+    DCP_TRY(dict_lasso<T>(h, Y, (const R*)nullptr, 0, D, X, Nb, F, K, alpha, lasso_tol, lasso_iter,
+                          lasso_method, &it, lw));
     if (lasso_it) *lasso_it = it;
     return dict_local_stats<T>(h, Y, X, Nb, F, K, stats, dw);
 }
@@ -59,17 +80,17 @@ inline int dict_stats_api(dcp_handle* h, const T* Y, T* X, const T* D, int64_t N
                           int* lasso_it) {
     DCP_TRY(dict_check<T>(h, Y, X, D, Nb, F, K));
     if (!stats) return fail(h, DCP_ERR_INVALID, "stats is null");
-    if (lasso_method < DCP_LASSO_ISTA || lasso_method > DCP_LASSO_CD)
+    if (!dict_lasso_method_ok(lasso_method))
         return fail(h, DCP_ERR_INVALID, "bad lasso method");
     DCP_HIP_OK(h, hipSetDevice(h->device));
     WsPlan plan;
-    lasso_plan<T>(plan, Nb, F, K, 0, lasso_method);
+    lasso_plan<T>(plan, Nb, F, K, 0, lasso_method & ~DCP_LASSO_POSITIVE);
     dict_plan_extra<T>(plan, Nb, F, K);
     DCP_TRY(ws_reserve(h, plan.total));
     ws_reset(h);
     LassoWs<T> lw;
     DictWs<T> dw;
-    DCP_TRY(lasso_carve<T>(h, lw, Nb, F, K, 0, lasso_method));
+    DCP_TRY(lasso_carve<T>(h, lw, Nb, F, K, 0, lasso_method & ~DCP_LASSO_POSITIVE));
     DCP_TRY(dict_carve_extra<T>(h, dw, Nb, F, K));
     return dict_stats_core<T>(h, Y, X, D, Nb, F, K, alpha, lasso_method, lasso_iter, lasso_tol, stats,
                               lasso_it, lw, dw);
@@ -103,18 +124,18 @@ inline int dict_step_api(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, T
     typedef real_t<T> R;
     DCP_TRY(dict_check<T>(h, Y, X, D, Nb, F, K));
     if (!Dnew || !A || !B || !maxdiff_host) return fail(h, DCP_ERR_INVALID, "null pointer");
-    if (lasso_method < DCP_LASSO_ISTA || lasso_method > DCP_LASSO_CD)
+    if (!dict_lasso_method_ok(lasso_method))
         return fail(h, DCP_ERR_INVALID, "bad lasso method");
     DCP_HIP_OK(h, hipSetDevice(h->device));
     WsPlan plan;
-    lasso_plan<T>(plan, Nb, F, K, 0, lasso_method);
+    lasso_plan<T>(plan, Nb, F, K, 0, lasso_method & ~DCP_LASSO_POSITIVE);
     dict_plan_extra<T>(plan, Nb, F, K);
     plan.add<T>((size_t)K * (F + K));
     DCP_TRY(ws_reserve(h, plan.total));
     ws_reset(h);
     LassoWs<T> lw;
     DictWs<T> dw;
-    DCP_TRY(lasso_carve<T>(h, lw, Nb, F, K, 0, lasso_method));
+    DCP_TRY(lasso_carve<T>(h, lw, Nb, F, K, 0, lasso_method & ~DCP_LASSO_POSITIVE));
     DCP_TRY(dict_carve_extra<T>(h, dw, Nb, F, K));
     T* stats = ws_alloc<T>(h, (size_t)K * (F + K));
     if (!stats) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
@@ -138,12 +159,12 @@ inline int dict_mask_step_api(dcp_handle* h, const T* Y, const real_t<T>* M, T* 
     typedef real_t<T> R;
     DCP_TRY(dict_check<T>(h, Y, X, D, Nb, F, K));
     if (!M || !Dnew || !A3 || !B || !maxdiff_host) return fail(h, DCP_ERR_INVALID, "null pointer");
-    if (lasso_method < DCP_LASSO_ISTA || lasso_method > DCP_LASSO_CD)
+    if (!dict_lasso_method_ok(lasso_method))
         return fail(h, DCP_ERR_INVALID, "bad lasso method");
     DCP_HIP_OK(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
     WsPlan plan;
-    lasso_plan<T>(plan, Nb, F, K, 2, lasso_method);
+    lasso_plan<T>(plan, Nb, F, K, 2, lasso_method & ~DCP_LASSO_POSITIVE);
     dict_plan_extra<T>(plan, Nb, F, K);
     plan.add<T>((size_t)Nb * F);   // y o m
     plan.add<T>((size_t)K * F);    // x^H (y o m)
@@ -151,19 +172,13 @@ inline int dict_mask_step_api(dcp_handle* h, const T* Y, const real_t<T>* M, T* 
     ws_reset(h);
     LassoWs<T> lw;
     DictWs<T> dw;
-    DCP_TRY(lasso_carve<T>(h, lw, Nb, F, K, 2, lasso_method));
+    DCP_TRY(lasso_carve<T>(h, lw, Nb, F, K, 2, lasso_method & ~DCP_LASSO_POSITIVE));
     DCP_TRY(dict_carve_extra<T>(h, dw, Nb, F, K));
     T* Ym = ws_alloc<T>(h, (size_t)Nb * F);
     T* sB = ws_alloc<T>(h, (size_t)K * F);
     if (!Ym || !sB) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
     int it = 0;
-    if constexpr (scalar_traits<T>::is_complex) {
-        DCP_TRY((lasso_solve<T, PROX_COMPLEX>(h, Y, M, 2, D, X, Nb, F, K, (R)alpha, (R)lasso_tol,
-                                              lasso_iter, lasso_method, &it, lw)));
-    } else {
-        DCP_TRY((lasso_solve<T, PROX_REAL>(h, Y, M, 2, D, X, Nb, F, K, (R)alpha, (R)lasso_tol,
-                                           lasso_iter, lasso_method, &it, lw)));
-    }
+    DCP_TRY(dict_lasso<T>(h, Y, M, 2, D, X, Nb, F, K, alpha, lasso_tol, lasso_iter, lasso_method, &it, lw));
     if (lasso_it) *lasso_it = it;
     // A3 <- beta A3 + x^H (x (x) m)
     hipLaunchKernelGGL((dict_mask_gram_kernel<T>), dim3((unsigned)F), dim3(256), 0, st, (const T*)X, M,

@@ -24,6 +24,7 @@
 #include "handle.hpp"
 #include "kernels_small.hpp"
 #include "nmf_impl.hpp"  // DCP_LAUNCH_OK, column_sums
+#include "lasso_extra.hpp"  // parallel_cd and admm kernels
 
 namespace dcp {
 
@@ -174,7 +175,10 @@ __global__ void __launch_bounds__(256) gershgorin_finish_kernel(const R* __restr
         best = (acc > best || acc != acc) ? acc : best;
     }
     R m = block_max_256(best, sh);
-    if (threadIdx.x == 0) Linv[0] = R(1) / m;
+    if (threadIdx.x == 0) {
+        Linv[0] = R(1) / m;
+        Linv[2] = m;    // the bound itself (parallel_cd: p = int(K / bound), lasso.py:468)
+    }
 }
 
 // out[f] = v[f] / count   (mean over the batch of the mask, lasso.py:300-303)
@@ -368,7 +372,9 @@ struct LassoWs {
     R* rowscale = nullptr;  // [N]
     R* mbar = nullptr;   // [F]
     R* part = nullptr;   // column-sum partials [64, F]
-    R* scal = nullptr;   // [4]: Linv, nvalid
+    R* scal = nullptr;   // [4]: Linv, nvalid, L
+    work_t<T>* inv_a = nullptr;  // admm: K x K work matrices (ping-pong) or the [N,K,K] per-row systems
+    work_t<T>* inv_b = nullptr;
     R* gpart = nullptr;  // [64, K] Gershgorin column-sum stripes
     float* ext1 = nullptr;  // complex64: real extended image of a [K,F] operand (4KF floats)
     float* ext2 = nullptr;  // complex64: real extended image of AAt (4K^2 floats)
@@ -386,8 +392,17 @@ inline void lasso_plan(WsPlan& p, int64_t N, int64_t F, int64_t K, int mask_ndim
     if (mask_ndim == 2) p.add<T>((size_t)K * F);
     p.add<T>((size_t)kMaxSplits * K * K);
     for (int i = 0; i < 4; ++i) p.add<T>((size_t)N * K);
-    if (method == DCP_LASSO_CD && mask_ndim != 2) p.add<T>((size_t)N * K);
+    if ((method == DCP_LASSO_CD || method == DCP_LASSO_PARALLEL_CD) && mask_ndim != 2)
+        p.add<T>((size_t)N * K);
     if (mask_ndim == 2) p.add<T>((size_t)N * F);
+    if (method == DCP_LASSO_ADMM) {
+        if (mask_ndim == 2) {
+            p.add<work_t<T> >((size_t)N * K * K);
+        } else {
+            p.add<work_t<T> >((size_t)K * K);
+            p.add<work_t<T> >((size_t)K * K);
+        }
+    }
     for (int i = 0; i < 4; ++i) p.add<R>((size_t)K);
     p.add<R>((size_t)N);
     p.add<R>((size_t)F);
@@ -413,8 +428,19 @@ inline int lasso_carve(dcp_handle* h, LassoWs<T>& w, int64_t N, int64_t F, int64
     w.slab_count = (size_t)kMaxSplits * K * K;
     w.slabs = ws_alloc<T>(h, w.slab_count);
     for (int i = 0; i < 4; ++i) w.xb[i] = ws_alloc<T>(h, (size_t)N * K);
-    if (method == DCP_LASSO_CD && mask_ndim != 2) w.G = ws_alloc<T>(h, (size_t)N * K);
+    const bool wants_g = (method == DCP_LASSO_CD || method == DCP_LASSO_PARALLEL_CD) && mask_ndim != 2;
+    if (wants_g) w.G = ws_alloc<T>(h, (size_t)N * K);
     if (mask_ndim == 2) w.T1 = ws_alloc<T>(h, (size_t)N * F);
+    if (method == DCP_LASSO_ADMM) {
+        if (mask_ndim == 2) {
+            w.inv_a = ws_alloc<work_t<T> >(h, (size_t)N * K * K);
+        } else {
+            w.inv_a = ws_alloc<work_t<T> >(h, (size_t)K * K);
+            w.inv_b = ws_alloc<work_t<T> >(h, (size_t)K * K);
+            if (!w.inv_b) return fail(h, DCP_ERR_INTERNAL, "lasso workspace plan mismatch");
+        }
+        if (!w.inv_a) return fail(h, DCP_ERR_INTERNAL, "lasso workspace plan mismatch");
+    }
     w.s = ws_alloc<R>(h, (size_t)K);
     w.alphak = ws_alloc<R>(h, (size_t)K);
     w.tolk = ws_alloc<R>(h, (size_t)K);
@@ -433,7 +459,7 @@ inline int lasso_carve(dcp_handle* h, LassoWs<T>& w, int64_t N, int64_t F, int64
     if (!w.An || !w.yAt || !w.AAt || !w.slabs || !w.xb[3] || !w.s || !w.alphak || !w.tolk ||
         !w.akk || !w.rowscale || !w.mbar || !w.part || !w.scal || !w.gpart || !w.flag ||
         (mask_ndim != 0 && !w.Ym) || (mask_ndim == 2 && (!w.Am || !w.T1)) ||
-        (method == DCP_LASSO_CD && mask_ndim != 2 && !w.G))
+        (wants_g && !w.G))
         return fail(h, DCP_ERR_INTERNAL, "lasso workspace plan mismatch");
     return DCP_OK;
 }
@@ -462,12 +488,35 @@ inline int read_flag(dcp_handle* h, int* flag_dev, int* host_flag, bool* violate
     return DCP_OK;
 }
 
+// scal[0] = 1 / L, scal[2] = L for L = max_j sum_i |M[i, j]|  (eigen.py:20)
+template <class T>
+inline int gershgorin_bound(dcp_handle* h, const T* M, int K, LassoWs<T>& w) {
+    typedef real_t<T> R;
+    const int stripes = K >= 64 ? 64 : K;
+    const long rows_per = (K + stripes - 1) / stripes;
+    hipLaunchKernelGGL((colabs_partial_kernel<T>), dim3(grid_for(K, 64), stripes), dim3(256), 0,
+                       h->stream, M, (long)K, rows_per, w.gpart);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    hipLaunchKernelGGL((gershgorin_finish_kernel<R>), dim3(1), dim3(256), 0, h->stream,
+                       (const R*)w.gpart, (long)K, stripes, w.scal);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    return DCP_OK;
+}
+
+// Inputs of the two solvers that need more than (alpha, tol, maxiter).
+struct LassoExtra {
+    const int* order = nullptr;   // parallel_cd: device int32 [order_rows, K] shuffle table
+    int64_t order_rows = 0;
+    double rho = 1.0;             // admm
+};
+
 // solve_fastpath (lasso.py:97-189).  Y [N,F], A [K,F], X [N,K] (in: initial estimate, out:
 // solution), mask: null, [F] (mask_ndim 1) or [N,F] (mask_ndim 2).  *it_out as the reference.
 template <class T, int PROX>
 inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mask_ndim, const T* A,
                        T* X, int64_t N64, int64_t F64, int64_t K64, real_t<T> alpha, real_t<T> tol,
-                       int maxiter, int method, int* it_out, LassoWs<T>& w) {
+                       int maxiter, int method, int* it_out, LassoWs<T>& w,
+                       const LassoExtra& extra = LassoExtra()) {
     typedef real_t<T> R;
     hipStream_t st = h->stream;
     const int N = (int)N64, F = (int)F64, K = (int)K64;
@@ -522,9 +571,142 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
     int it = maxiter - 1;
     T* result = xcur;
 
-    if (method == DCP_LASSO_CD && mask_ndim != 2) {
-        // ---------------- coordinate descent, Gram form ----------------
+    // ---- parallel_cd: p = int(K / Gershgorin(A A^H)), unmasked Gram matrix in every variant
+    //      (lasso.py:464-470, 503-509); p <= 1 falls back to plain coordinate descent ----
+    bool have_gram = false;
+    int pcd_p = 0;
+    if (method == DCP_LASSO_PARALLEL_CD) {
         DCP_TRY(gram_kk<T>(h, w.An, w.An, K, F, w, w.AAt));
+        have_gram = true;
+        DCP_TRY(gershgorin_bound<T>(h, w.AAt, K, w));
+        R* host_l = reinterpret_cast<R*>(reinterpret_cast<char*>(hostv) + 16);
+        DCP_HIP_OK(h, hipMemcpyAsync(host_l, w.scal + 2, sizeof(R), hipMemcpyDeviceToHost, st));
+        DCP_HIP_OK(h, hipStreamSynchronize(st));
+        const R ratio = (R)K / host_l[0];
+        pcd_p = (ratio == ratio && ratio < R(2147483647)) ? (int)ratio : 0;
+        if (pcd_p <= 1) {
+            if (mask_ndim == 2)
+                return fail(h, DCP_ERR_REF_TYPEERROR,
+                            "parallel_cd with a full mask and p <= 1: the reference's fallback call "
+                            "raises TypeError (lasso.py:509)");
+            method = DCP_LASSO_CD;
+        } else if (extra.order == nullptr || extra.order_rows < (int64_t)maxiter) {
+            return fail(h, DCP_ERR_INVALID, "parallel_cd needs a shuffle table of >= maxiter rows");
+        }
+    }
+
+    if (method == DCP_LASSO_PARALLEL_CD) {
+        // ---------------- parallel coordinate descent (lasso.py:476-484, 515-523) ----------------
+        T* X0 = xcur;
+        T* Xn = w.xb[1];
+        T* Xnew = w.xb[2];
+        bool converged = false;
+        for (int i = 0; i < maxiter; ++i) {
+            const int check = (i % 10 == 0) ? 1 : 0;
+            if (check) DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
+            EpiPcdStep<T, PROX> epi{w.yAt, X0, Xnew, Xn, (long)K, w.alphak, w.tolk, rowscale,
+                                    extra.order + (long)i * K, pcd_p, check, w.flag};
+            if (mask_ndim == 2) {
+                GemmArgs<T> a1;   // T1 = (x0 An) o M
+                a1.A = X0; a1.lda = K; a1.B = w.An; a1.ldb = F; a1.M = N; a1.N = F; a1.K = K;
+                a1.ext_ws = w.ext1;
+                DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a1, EpiMulMask<T>{mask, F, w.T1, F})));
+                GemmArgs<T> a2;   // back = T1 An^H
+                a2.A = w.T1; a2.lda = F; a2.B = w.An; a2.ldb = F; a2.M = N; a2.N = K; a2.K = F;
+                a2.conjB = true;
+                a2.ext_ws = w.ext1;
+                DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a2, epi)));
+            } else {
+                GemmArgs<T> a;    // back = x0 AAt
+                a.A = X0; a.lda = K; a.B = w.AAt; a.ldb = K; a.M = N; a.N = K; a.K = K;
+                a.ext_ws = w.ext2;
+                DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, epi)));
+            }
+            if (check) {
+                bool viol = true;
+                DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
+                if (!viol) { it = i; result = Xnew; converged = true; break; }   // lasso.py:479-480
+            }
+            T* t = X0; X0 = Xn; Xn = t;                                          // x0 += dx * select
+        }
+        if (!converged) result = X0;
+    } else if (method == DCP_LASSO_ADMM && mask_ndim != 2) {
+        // ---------------- ADMM (lasso.py:586-618) ----------------
+        typedef work_t<T> TW;
+        const R rho = (R)extra.rho;
+        DCP_TRY(gram_kk<T>(h, w.An, w.An, K, F, w, w.AAt));
+        hipLaunchKernelGGL((inv_load_kernel<T>), dim3(grid_for((long)K * K)), dim3(256), 0, st,
+                           (const T*)w.AAt, K, extra.rho, w.inv_a);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        TW* src = w.inv_a;
+        TW* dst = w.inv_b;
+        for (int k = 0; k < K; ++k) {
+            hipLaunchKernelGGL((gj_step_kernel<TW>), dim3(grid_for((long)K * K)), dim3(256), 0, st,
+                               (const TW*)src, dst, K, k);
+            TW* t = src; src = dst; dst = t;
+        }
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        T* Minv = w.AAt;     // (AAt + rho I)^-1 replaces AAt
+        hipLaunchKernelGGL((inv_store_kernel<T>), dim3(grid_for((long)K * K)), dim3(256), 0, st,
+                           (const TW*)src, (long)K * K, Minv);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        T* U = w.xb[1];
+        T* V = w.xb[2];
+        T* Vn = w.xb[3];
+        hipLaunchKernelGGL((admm_init_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st,
+                           (const T*)w.yAt, (const T*)xcur, (long)N * K, rho, U, V);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        for (int i = 0; i < maxiter; ++i) {
+            const int check = (i % 10 == 0) ? 1 : 0;
+            if (check) DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
+            EpiAdmmStep<T, PROX> epi{w.yAt, xcur, U, Vn, (long)K, w.alphak, w.tolk, rho, check, w.flag};
+            GemmArgs<T> a;    // x_new = V Minv
+            a.A = V; a.lda = K; a.B = Minv; a.ldb = K; a.M = N; a.N = K; a.K = K;
+            a.ext_ws = w.ext2;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, epi)));
+            if (check) {
+                bool viol = true;
+                DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
+                if (!viol) { it = i; break; }                                    // lasso.py:612-614
+            }
+            T* t = V; V = Vn; Vn = t;
+        }
+        result = xcur;
+    } else if (method == DCP_LASSO_ADMM) {
+        // ---------------- ADMM with a 2-D mask: one K x K system per row (lasso.py:621-657) --------
+        typedef work_t<T> TW;
+        const R rho = (R)extra.rho;
+        if ((size_t)2 * K * sizeof(TW) > 65536)
+            return fail(h, DCP_ERR_UNSUPPORTED, "masked admm: n_features too large for the per-row inverse");
+        hipLaunchKernelGGL((admm_mask_system_kernel<T>), dim3(N), dim3(256), 0, st, (const T*)w.An, mask,
+                           K, (long)F, extra.rho, w.inv_a);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        hipLaunchKernelGGL((gj_batched_kernel<TW>), dim3(N), dim3(256), (size_t)2 * K * sizeof(TW), st,
+                           w.inv_a, K);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        T* U = w.xb[1];
+        T* V = w.xb[2];
+        hipLaunchKernelGGL((admm_init_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st,
+                           (const T*)w.yAt, (const T*)xcur, (long)N * K, rho, U, V);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        for (int i = 0; i < maxiter; ++i) {
+            const int check = (i % 10 == 0) ? 1 : 0;
+            if (check) DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
+            hipLaunchKernelGGL((admm_mask_step_kernel<T, PROX>), dim3(N), dim3(256),
+                               (size_t)K * sizeof(T), st, (const T*)w.yAt, (const TW*)w.inv_a, xcur, U, V,
+                               K, (const R*)w.alphak, (const R*)w.rowscale, (const R*)w.tolk, rho, check,
+                               w.flag);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+            if (check) {
+                bool viol = true;
+                DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
+                if (!viol) { it = i; break; }
+            }
+        }
+        result = xcur;
+    } else if (method == DCP_LASSO_CD && mask_ndim != 2) {
+        // ---------------- coordinate descent, Gram form ----------------
+        if (!have_gram) DCP_TRY(gram_kk<T>(h, w.An, w.An, K, F, w, w.AAt));
         {   // g = yAt - x AAt
             GemmArgs<T> a;
             a.A = xcur; a.lda = K; a.B = w.AAt; a.ldb = K; a.M = N; a.N = K; a.K = K;
@@ -610,16 +792,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         } else {
             DCP_TRY(gram_kk<T>(h, w.An, w.An, K, F, w, w.AAt));
         }
-        {
-            const int stripes = K >= 64 ? 64 : K;
-            const long rows_per = (K + stripes - 1) / stripes;
-            hipLaunchKernelGGL((colabs_partial_kernel<T>), dim3(grid_for(K, 64), stripes), dim3(256), 0,
-                               st, (const T*)w.AAt, (long)K, rows_per, w.gpart);
-            DCP_LAUNCH_OK(h, hipGetLastError());
-            hipLaunchKernelGGL((gershgorin_finish_kernel<R>), dim3(1), dim3(256), 0, st,
-                               (const R*)w.gpart, (long)K, stripes, w.scal);
-            DCP_LAUNCH_OK(h, hipGetLastError());
-        }
+        DCP_TRY(gershgorin_bound<T>(h, w.AAt, K, w));
 
         // Buffer roles (pointers rotate over the four [N,K] buffers):
         //   P = the iterate the stop test compares with (the reference's x0)

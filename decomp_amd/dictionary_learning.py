@@ -54,13 +54,8 @@ def solve(y, D, alpha, x=None, tol=1.0e-3,
     get_array_module(y, D, x_given, mask)                                # :78
     if method != 'block_cd':                                             # :109-111
         raise NotImplementedError('Method %s is not yet implemented' % method)
-    base = lasso_method[:-4] if lasso_method.endswith('_pos') else lasso_method
-    if base not in lasso._METHOD_CODE:
-        raise NotImplementedError('lasso_method %s is not implemented on the GPU path'
-                                  % lasso_method)
-    if lasso_method.endswith('_pos'):
-        raise NotImplementedError('non-negative lasso inside dictionary learning is not '
-                                  'implemented on the GPU path')
+    lasso._dict_method_code(lasso_method)      # NotImplementedError for unknown solvers
+    assert _arrays.np_dtype(D).kind != 'c' or not lasso_method.endswith('_pos')   # lasso.py:92
 
     yd = _arrays.to_device(y)
     dev = yd.device.index
@@ -95,7 +90,7 @@ def solve_cd(y, D, alpha, x, tol, minibatch, maxiter,
     sfx = _arrays.suffix(D)
     lib, h = _arrays.lib_handle(D)
     step = getattr(lib, 'dcp_dict_step_' + sfx)
-    code = lasso._METHOD_CODE[lasso_method]
+    code = lasso._dict_method_code(lasso_method)
     index = np.arange(y.size)                                            # :120
     A = torch.zeros((K, K), dtype=D.dtype, device=D.device)              # :122-123
     B = torch.zeros((K, F), dtype=D.dtype, device=D.device)
@@ -136,7 +131,7 @@ def solve_cd_mask(y, D, alpha, x, tol, minibatch, maxiter,
     sfx = _arrays.suffix(D)
     lib, h = _arrays.lib_handle(D)
     step = getattr(lib, 'dcp_dict_mask_step_' + sfx)
-    code = lasso._METHOD_CODE[lasso_method]
+    code = lasso._dict_method_code(lasso_method)
     index = np.arange(y.size)
     A = torch.zeros((K, F, K), dtype=D.dtype, device=D.device)           # :179
     B = torch.zeros((K, F), dtype=D.dtype, device=D.device)

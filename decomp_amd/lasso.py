@@ -2,13 +2,16 @@
 
 Same entry points, argument meaning, return convention and error behaviour as the
 reference's decomp/lasso.py:19-189.  Everything after validation (``solve_fastpath``:
-row-normalising A, the ista / acc_ista / fista / cd iterations, masks, complex data)
-runs in libdecomp_hip.so: see include/decomp_hip.h ``dcp_lasso_*`` and
-decomp_amd/csrc/lasso_impl.hpp.
+row-normalising A, the ista / acc_ista / fista / cd / parallel_cd / admm iterations,
+masks, complex data) runs in libdecomp_hip.so: see include/decomp_hip.h ``dcp_lasso_*``
+and decomp_amd/csrc/lasso_impl.hpp, lasso_extra.hpp.
 
-Not on the GPU path (out of scope): 'parallel_cd' (host RNG shuffle per
-iteration) and 'admm' (batched matrix inverse); they are accepted as method names, as
-in the reference, and raise NotImplementedError.
+'parallel_cd' consumes a host RNG stream in the reference (``RandomState(0).shuffle`` of
+the commit vector every iteration, lasso.py:463,481): this module generates that stream
+and hands it to the library as a table (``dcp_lasso_pcd_*``).
+'admm' keeps the problem dtype; the reference silently promotes float32 / complex64
+problems to double there (its ``rho * eye(K)`` is float64, lasso.py:603) -- same
+iteration, the result agrees to the input precision.
 """
 import ctypes
 
@@ -23,7 +26,36 @@ AVAILABLE_NNLS_METHODS = ['ista_pos', 'cd_pos', 'acc_ista_pos', 'fista_pos',
                           'parallel_cd_pos', 'admm_pos']
 _JITTER = 1.0e-15
 _METHOD_CODE = {'ista': _hip.LASSO_ISTA, 'acc_ista': _hip.LASSO_ACC_ISTA,
-                'fista': _hip.LASSO_FISTA, 'cd': _hip.LASSO_CD}
+                'fista': _hip.LASSO_FISTA, 'cd': _hip.LASSO_CD,
+                'parallel_cd': _hip.LASSO_PARALLEL_CD, 'admm': _hip.LASSO_ADMM}
+
+
+def _dict_method_code(lasso_method):
+    """Code of a solver name for the dcp_dict_* entry points ('_pos' -> DCP_LASSO_POSITIVE).
+    'parallel_cd' is not available inside the fused dictionary step (its RNG stream lives
+    on the host)."""
+    base = lasso_method[:-4] if lasso_method.endswith('_pos') else lasso_method
+    if base not in _METHOD_CODE or base == 'parallel_cd':
+        raise NotImplementedError('lasso_method %s is not implemented inside the GPU '
+                                  'dictionary step' % lasso_method)
+    code = _METHOD_CODE[base]
+    if lasso_method.endswith('_pos'):
+        code |= _hip.LASSO_POSITIVE
+    return code
+
+
+def _pcd_shuffle_table(K, rows):
+    """The reference's RNG stream for parallel_cd (lasso.py:463,481): it shuffles ONE 0/1
+    vector cumulatively with RandomState(0); a shuffle's swaps do not depend on the
+    content, so row i of this table (arange(K) after i + 1 shuffles) reproduces the
+    vector of iteration i as ``table[i] < p`` for whatever p the device finds."""
+    rng = np.random.RandomState(0)
+    idx = np.arange(K, dtype=np.int32)
+    table = np.empty((rows, K), dtype=np.int32)
+    for i in range(rows):
+        rng.shuffle(idx)
+        table[i] = idx
+    return table
 
 
 class _ZerosLike(object):
@@ -39,7 +71,8 @@ def solve(y, A, alpha, x=None, tol=1.0e-3, method='ista', maxiter=1000,
 
     y: [..., n_channels], x: [..., n_features], A: [n_features, n_channels]; float or
     complex, all of one dtype; mask: float, y's shape or [n_channels].
-    method: 'ista' | 'acc_ista' | 'fista' | 'cd' (+ '_pos' for non-negative x).
+    method: 'ista' | 'acc_ista' | 'fista' | 'cd' | 'parallel_cd' | 'admm'
+    (+ '_pos' for non-negative x).
     Returns (it, x) as the reference does.
     """
     kind = get_array_module(y, A, x, mask)                            # lasso.py:71
@@ -75,9 +108,11 @@ def solve_fastpath(y, A, alpha, x, tol, maxiter, method, xp, mask=None, **kwargs
     if method[-4:] == '_pos':
         method = method[:-4]
         positive = True
-    if method not in _METHOD_CODE:
-        raise NotImplementedError('Method ' + method + ' is not implemented on the GPU path '
-                                  '(only ista, acc_ista, fista, cd and their _pos variants).')
+    if method not in _METHOD_CODE:                                    # lasso.py:157-159
+        raise NotImplementedError('Method ' + method + ' is not yet implemented.')
+    rho = 1.0
+    if method == 'admm':                                              # lasso.py:155 (**kwargs)
+        rho = float(kwargs.pop('rho', 1.0))
     if kwargs:
         raise TypeError('solve_fastpath() got an unexpected keyword argument %r'
                         % sorted(kwargs)[0])
@@ -111,11 +146,27 @@ def solve_fastpath(y, A, alpha, x, tol, maxiter, method, xp, mask=None, **kwargs
         md = md.contiguous()
     lib, h = _arrays.lib_handle(yd)
     it = ctypes.c_int(0)
-    fn = getattr(lib, 'dcp_lasso_' + sfx)
-    rc = fn(h, _arrays.ptr(y2.contiguous()), _arrays.ptr(md), mask_ndim, _arrays.ptr(Ad),
-            _arrays.ptr(xd), N, F, K, float(alpha), float(tol), int(maxiter),
-            _METHOD_CODE[method], 1 if positive else 0, ctypes.byref(it))
-    _hip.check(h, rc, 'dcp_lasso_' + sfx)
+    y2 = y2.contiguous()
+    if method == 'parallel_cd':
+        table = torch.from_numpy(_pcd_shuffle_table(K, max(int(maxiter), 1))).to(yd.device)
+        name = 'dcp_lasso_pcd_' + sfx
+        rc = getattr(lib, name)(h, _arrays.ptr(y2), _arrays.ptr(md), mask_ndim, _arrays.ptr(Ad),
+                                _arrays.ptr(xd), N, F, K, float(alpha), float(tol), int(maxiter),
+                                1 if positive else 0, _arrays.ptr(table), table.shape[0],
+                                ctypes.byref(it))
+        if rc == _hip.ERR_REF_TYPEERROR:                              # lasso.py:509
+            raise TypeError("_solve_cd_mask() missing 1 required positional argument: 'xp'")
+    elif method == 'admm':
+        name = 'dcp_lasso_admm_' + sfx
+        rc = getattr(lib, name)(h, _arrays.ptr(y2), _arrays.ptr(md), mask_ndim, _arrays.ptr(Ad),
+                                _arrays.ptr(xd), N, F, K, float(alpha), float(tol), int(maxiter),
+                                1 if positive else 0, rho, ctypes.byref(it))
+    else:
+        name = 'dcp_lasso_' + sfx
+        rc = getattr(lib, name)(h, _arrays.ptr(y2), _arrays.ptr(md), mask_ndim, _arrays.ptr(Ad),
+                                _arrays.ptr(xd), N, F, K, float(alpha), float(tol), int(maxiter),
+                                _METHOD_CODE[method], 1 if positive else 0, ctypes.byref(it))
+    _hip.check(h, rc, name)
     out = xd.reshape(batch_shape + (K,))
     return it.value, _arrays.to_caller(out, kind)
 

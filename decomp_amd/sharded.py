@@ -147,7 +147,7 @@ class HipDictBackend(object):
         self.torch = torch
         self.sfx = _arrays.suffix(D)
         self.K, self.F = D.shape
-        self.code = lasso._METHOD_CODE[lasso_method]
+        self.code = lasso._dict_method_code(lasso_method)
         self.lasso_iter, self.lasso_tol, self.alpha = int(lasso_iter), float(lasso_tol), float(alpha)
         self.stats = torch.empty((self.K, self.F + self.K), dtype=D.dtype, device=D.device)
         rdt = torch.float32 if D.dtype in (torch.float32, torch.complex64) else torch.float64
@@ -229,8 +229,7 @@ def dictionary_learning_sharded(y, D, alpha, x=None, tol=1.0e-3, minibatch=None,
     from .utils.data import MinibatchData
     if minibatch is None:
         raise NotImplementedError('Only online methods are implemented. minibatch is required.')
-    if lasso_method not in lasso._METHOD_CODE:
-        raise NotImplementedError('lasso_method %s is not implemented on the GPU path' % lasso_method)
+    lasso._dict_method_code(lasso_method)      # NotImplementedError for unknown solvers
     init = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if init else 1
     rank = dist.get_rank(group) if init else 0

@@ -37,14 +37,18 @@ enum {
     DCP_ERR_HIP = -2,       /* a HIP runtime call failed */
     DCP_ERR_NOMEM = -3,     /* workspace allocation failed */
     DCP_ERR_INTERNAL = -4,  /* library bug (workspace plan mismatch, ...) */
-    DCP_ERR_UNSUPPORTED = -5
+    DCP_ERR_UNSUPPORTED = -5,
+    DCP_ERR_REF_TYPEERROR = -6  /* the reference raises TypeError on this input (lasso.py:509) */
 };
 
 /* likelihood codes: decomp/nmf_methods/grads.py:7-14 */
 enum { DCP_LIK_L2 = 0, DCP_LIK_KL = 1 };
 
-/* LASSO solver codes: decomp/lasso.py:13 (the starred subset of SURVEY 8a) */
-enum { DCP_LASSO_ISTA = 0, DCP_LASSO_ACC_ISTA = 1, DCP_LASSO_FISTA = 2, DCP_LASSO_CD = 3 };
+/* LASSO solver codes: decomp/lasso.py:13 */
+enum { DCP_LASSO_ISTA = 0, DCP_LASSO_ACC_ISTA = 1, DCP_LASSO_FISTA = 2, DCP_LASSO_CD = 3,
+       DCP_LASSO_PARALLEL_CD = 4, DCP_LASSO_ADMM = 5 };
+/* dcp_dict_*: OR this into lasso_method for the '_pos' (non-negative) solvers */
+enum { DCP_LASSO_POSITIVE = 0x100 };
 
 /* ---- lifetime ----------------------------------------------------------------- */
 int dcp_create(dcp_handle** out, int device);
@@ -206,6 +210,45 @@ int dcp_lasso_c64(dcp_handle* h, const void* Y, const float* mask, int mask_ndim
 int dcp_lasso_c128(dcp_handle* h, const void* Y, const double* mask, int mask_ndim, const void* A,
                    void* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
                    int method, int positive, int* it_out);
+
+/* decomp/lasso.py:448-523 `_solve_parallel_cd(_mask)`: every iteration evaluates the unit-step
+ * proximal update of all coordinates and commits it on p = int(K / Gershgorin(A A^H)) of them,
+ * chosen by a 0/1 vector that the reference re-shuffles with np.random.RandomState(0) each
+ * iteration.  The RNG stream is host state, so the caller supplies it: `order` is a DEVICE
+ * int32 [order_rows, K] table, row i = arange(K) after i + 1 cumulative RandomState(0).shuffle
+ * calls (a shuffle's swap sequence does not depend on the array's content); coordinate k is
+ * committed in iteration i iff order[i, k] < p.  order_rows >= maxiter.  p <= 1: the library
+ * runs plain coordinate descent as the reference does (lasso.py:469-470); with a 2-D mask the
+ * reference's fallback call is broken (lasso.py:509) and DCP_ERR_REF_TYPEERROR is returned. */
+int dcp_lasso_pcd_f32(dcp_handle* h, const float* Y, const float* mask, int mask_ndim, const float* A,
+                      float* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                      int positive, const int32_t* order, int64_t order_rows, int* it_out);
+int dcp_lasso_pcd_f64(dcp_handle* h, const double* Y, const double* mask, int mask_ndim, const double* A,
+                      double* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                      int positive, const int32_t* order, int64_t order_rows, int* it_out);
+int dcp_lasso_pcd_c64(dcp_handle* h, const void* Y, const float* mask, int mask_ndim, const void* A,
+                      void* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                      int positive, const int32_t* order, int64_t order_rows, int* it_out);
+int dcp_lasso_pcd_c128(dcp_handle* h, const void* Y, const double* mask, int mask_ndim, const void* A,
+                       void* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                       int positive, const int32_t* order, int64_t order_rows, int* it_out);
+
+/* decomp/lasso.py:586-657 `_solve_admm(_mask)` with penalty rho (dcp_lasso_* with
+ * DCP_LASSO_ADMM uses rho = 1.0 like solve_fastpath).  (A A^H + rho I)^-1 is formed on the
+ * device in double precision (math_utils/linalg.py:9-16); a 2-D mask needs one K x K system
+ * per row (N K^2 workspace, K <= 2048). */
+int dcp_lasso_admm_f32(dcp_handle* h, const float* Y, const float* mask, int mask_ndim, const float* A,
+                       float* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                       int positive, double rho, int* it_out);
+int dcp_lasso_admm_f64(dcp_handle* h, const double* Y, const double* mask, int mask_ndim, const double* A,
+                       double* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                       int positive, double rho, int* it_out);
+int dcp_lasso_admm_c64(dcp_handle* h, const void* Y, const float* mask, int mask_ndim, const void* A,
+                       void* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                       int positive, double rho, int* it_out);
+int dcp_lasso_admm_c128(dcp_handle* h, const void* Y, const double* mask, int mask_ndim, const void* A,
+                        void* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
+                        int positive, double rho, int* it_out);
 
 /* ---- online dictionary learning (block coordinate descent) -------------------------- */
 /* One minibatch step of decomp/dictionary_learning.py:135-164 (solve_cd), split at the

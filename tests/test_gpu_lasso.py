@@ -114,13 +114,14 @@ def test_mask_equivalences():
         assert np.allclose(xa, xb, atol=1e-5, rtol=1e-3), method
 
 
-def test_errors_and_unsupported_methods():
+def test_errors():
     from decomp_amd import lasso
     y, A = np.random.randn(4, 6), np.random.randn(3, 6)
-    with pytest.raises(NotImplementedError):
-        lasso.solve(y, A, 0.1, method='admm')
-    with pytest.raises(NotImplementedError):
-        lasso.solve(y, A, 0.1, method='parallel_cd')
+    with pytest.raises(ValueError):            # unknown method (lasso.py:88-90)
+        lasso.solve(y, A, 0.1, method='newton')
+    with pytest.raises(ValueError):            # nnls default method quirk (nnls.py:4-7)
+        from decomp_amd import nnls
+        nnls.solve(y, A, 0.1)
     with pytest.raises(AssertionError):        # negative mask (lasso.py:78)
         lasso.solve(y, A, 0.1, mask=-np.ones((4, 6)))
     with pytest.raises(AssertionError):        # complex + _pos (lasso.py:92)
