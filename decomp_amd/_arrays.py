@@ -88,6 +88,8 @@ def to_caller(t, kind):
     """Back to the caller's array kind."""
     if t is None:
         return None
+    if isinstance(t, np.ndarray):     # streamed containers hand back host arrays
+        return t
     if kind == 'torch':
         return t
     return t.cpu().numpy()

@@ -199,6 +199,120 @@ __global__ void __launch_bounds__(256) calib_read_kernel(const float* __restrict
 
 }  // namespace
 
+// Row mover for the minibatch containers (decomp/utils/data.py:124-156, 214-313): dtype-agnostic,
+//   out[(out_index ? out_index[i] : i), :] = in[(in_index ? in_index[i] : i), :],  i < rows.
+// Either side may be PINNED HOST memory (the out-of-core container gathers a shuffled minibatch
+// straight over PCIe, 16 bytes per lane, no host-side shuffle pass).  One workgroup per
+// (row, 16 KiB chunk); rows whose byte length or base is not 16-byte aligned take the byte loop.
+template <int GROUPS>
+__global__ void __launch_bounds__(256 * GROUPS) move_rows_kernel(const unsigned char* __restrict__ in,
+                                                                 const long long* __restrict__ in_index,
+                                                                 unsigned char* __restrict__ out,
+                                                                 const long long* __restrict__ out_index,
+                                                                 long rows, long row_bytes, int chunks,
+                                                                 int vec_ok) {
+    // GROUPS > 1 (PCIe mover): the launch asks for the CU's whole LDS so that no compute
+    // workgroup shares the CU -- see move_rows() below.  The array is never touched.
+    extern __shared__ unsigned char move_rows_lds[];
+    const int tid = threadIdx.x & 255;
+    const long group = (long)blockIdx.x * GROUPS + (threadIdx.x >> 8);
+    const long ngroups = (long)gridDim.x * GROUPS;
+    if (vec_ok) {
+        // the matrix as a stream of 16-byte pieces; a unit = 1024 consecutive pieces (16 KiB,
+        // possibly several short rows), 4 pieces per lane, all loads issued before the stores
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const long P = row_bytes >> 4;              // pieces per row
+        const long total = rows * P;
+        const long units = (total + 1023) >> 10;
+        for (long unit = group; unit < units; unit += ngroups) {
+            u32x4 v[4];
+            long dst_off[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long g = (unit << 10) + tid + u * 256;
+                dst_off[u] = -1;
+                if (g < total) {
+                    const long i = g / P;
+                    const long o = (g - i * P) << 4;
+                    const long src_row = in_index ? (long)in_index[i] : i;
+                    const long dst_row = out_index ? (long)out_index[i] : i;
+                    v[u] = *reinterpret_cast<const u32x4*>(in + src_row * row_bytes + o);
+                    dst_off[u] = dst_row * row_bytes + o;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst_off[u] >= 0) *reinterpret_cast<u32x4*>(out + dst_off[u]) = v[u];
+        }
+    } else {
+        for (long wg = group; wg < rows * chunks; wg += ngroups) {
+            const long i = wg / chunks;
+            const int ch = (int)(wg - i * chunks);
+            const long src_row = in_index ? (long)in_index[i] : i;
+            const long dst_row = out_index ? (long)out_index[i] : i;
+            const unsigned char* s = in + src_row * row_bytes;
+            unsigned char* d = out + dst_row * row_bytes;
+            const long b0 = (long)ch * 16384;
+            const long b1 = min(row_bytes, b0 + 16384);
+            for (long o = b0 + tid; o < b1; o += 256) d[o] = s[o];
+        }
+    }
+}
+
+// Is p ordinary device memory?
+static bool is_device_memory(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+static int move_rows(dcp_handle* h, const void* in, const int64_t* in_index, void* out,
+                     const int64_t* out_index, int64_t rows, int64_t row_bytes) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!in || !out) return dcp::fail(h, DCP_ERR_INVALID, "null pointer");
+    if (rows < 0 || row_bytes < 0) return dcp::fail(h, DCP_ERR_INVALID, "negative size");
+    if (rows == 0 || row_bytes == 0) return DCP_OK;
+    const long chunks = (row_bytes + 16383) / 16384;
+    if (rows * chunks > 0x7fffffffL) return dcp::fail(h, DCP_ERR_INVALID, "too many row chunks");
+    const int vec_ok = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    const bool on_device = is_device_memory(in) && is_device_memory(out);
+    const long want = vec_ok ? (rows * (row_bytes >> 4) + 1023) / 1024 : rows * chunks;
+    const unsigned char* inb = reinterpret_cast<const unsigned char*>(in);
+    unsigned char* outb = reinterpret_cast<unsigned char*>(out);
+    const long long* ii = reinterpret_cast<const long long*>(in_index);
+    const long long* oi = reinterpret_cast<const long long*>(out_index);
+    if (on_device) {
+        const long cap = 8192;
+        hipLaunchKernelGGL(move_rows_kernel<1>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0,
+                           h->stream, inb, ii, outb, oi, (long)rows, (long)row_bytes, (int)chunks, vec_ok);
+    } else {
+        // One side is pinned host memory, reached over PCIe.  Waves that sit on PCIe latency clog
+        // the memory pipeline of their CU: a compute workgroup sharing that CU runs several times
+        // slower, and a one-round GEMM is as slow as its slowest workgroup (seen: 350 us -> 2 ms).
+        // So the mover takes a dozen CUs for itself -- 1024 threads and the CU's whole LDS per
+        // workgroup keep every other workgroup off them -- which is plenty to saturate the link
+        // (12 x 64 KiB in flight) and costs the overlapped compute < 5 % of the chip.
+        static bool raised = false;
+        const int lds_bytes = 160 * 1024;
+        if (!raised) {
+            DCP_HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&move_rows_kernel<4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            raised = true;
+        }
+        const long groups = (want + 3) / 4;
+        hipLaunchKernelGGL(move_rows_kernel<4>, dim3((unsigned)(groups < 12 ? groups : 12)), dim3(1024),
+                           lds_bytes, h->stream, inb, ii, outb, oi, (long)rows, (long)row_bytes,
+                           (int)chunks, vec_ok);
+    }
+    DCP_HIP_OK(h, hipGetLastError());
+    return DCP_OK;
+}
+
 extern "C" {
 
 int dcp_calib_read_f32(dcp_handle* h, const float* p, int64_t rows, int64_t cols, int pattern,
@@ -342,6 +456,18 @@ int dcp_gemm_c64(dcp_handle* h, int form, const void* A, const void* B, void* C,
                  int64_t K, int ksplits, int tile) {
     return gemm_api<c64>(h, form, reinterpret_cast<const c64*>(A), reinterpret_cast<const c64*>(B),
                          reinterpret_cast<c64*>(C), M, N, K, ksplits, tile);
+}
+
+int dcp_gather_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
+                          int64_t row_bytes, void* out) {
+    if (h && !index) return dcp::fail(h, DCP_ERR_INVALID, "null index");
+    return move_rows(h, in, index, out, nullptr, rows, row_bytes);
+}
+
+int dcp_scatter_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
+                           int64_t row_bytes, void* out) {
+    if (h && !index) return dcp::fail(h, DCP_ERR_INVALID, "null index");
+    return move_rows(h, in, nullptr, out, index, rows, row_bytes);
 }
 
 }  // extern "C"

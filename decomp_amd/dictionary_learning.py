@@ -20,7 +20,7 @@ import numpy as np
 from . import _arrays, _hip, lasso
 from ._arrays import get_array_module
 from .utils import assertion
-from .utils.data import MinibatchData, NoneIterator
+from .utils.data import MinibatchData, AsyncMinibatchData, NoneIterator
 
 _JITTER = 1.0e-15
 
@@ -51,31 +51,40 @@ def solve(y, D, alpha, x=None, tol=1.0e-3,
     if minibatch is None:                                                # :72-74
         raise NotImplementedError('Only online methods are implemented. '
                                   'minibatch is required.')
-    get_array_module(y, D, x_given, mask)                                # :78
+    if kind == 'numpy':
+        get_array_module(y, D, x_given, mask)                            # :78
     if method != 'block_cd':                                             # :109-111
         raise NotImplementedError('Method %s is not yet implemented' % method)
     lasso._dict_method_code(lasso_method)      # NotImplementedError for unknown solvers
     assert _arrays.np_dtype(D).kind != 'c' or not lasso_method.endswith('_pos')   # lasso.py:92
 
-    yd = _arrays.to_device(y)
-    dev = yd.device.index
-    Dd = _arrays.to_device(D, dev, copy=True)
+    Dd = _arrays.to_device(D, copy=True)
+    dev = Dd.device.index
+    rdt = torch.float32 if Dd.dtype in (torch.float32, torch.complex64) else torch.float64
+
+    def dataset(a, needs_update, real=False):
+        """dictionary_learning.py:87-97: with a device D, NumPy arrays stay in pinned host
+        memory and are streamed (AsyncMinibatchData); everything else is in-core."""
+        if kind == 'torch' and not _arrays.is_torch(a):
+            if real:
+                a = np.ascontiguousarray(a, dtype=_arrays._torch_to_np_dtype(rdt))
+            return AsyncMinibatchData(a, minibatch, needs_update=needs_update, device=dev)
+        t = _arrays.to_device(a, dev, copy=needs_update)
+        if real and t.dtype != rdt:
+            t = t.to(rdt)
+        return MinibatchData(t.contiguous(), minibatch)
+
+    ybat = dataset(y, False)                                             # :79-80
     if x_given is None:
-        xd = torch.ones(x.shape, dtype=Dd.dtype, device=Dd.device)
+        xbat = MinibatchData(torch.ones(x.shape, dtype=Dd.dtype, device=Dd.device), minibatch)
     else:
-        xd = _arrays.to_device(x_given, dev, copy=True)
-    ybat = MinibatchData(yd, minibatch)                                  # :79-80
-    xbat = MinibatchData(xd, minibatch)
+        xbat = dataset(x_given, True)
     rng = np.random.RandomState(random_seed)                             # :85
     if mask is None:
         it, Dout, xout = solve_cd(ybat, Dd, alpha, xbat, tol, minibatch, maxiter,
                                   lasso_method, lasso_iter, lasso_tol, rng, kind)
     else:
-        md = _arrays.to_device(mask, dev)
-        rdt = torch.float32 if Dd.dtype in (torch.float32, torch.complex64) else torch.float64
-        if md.dtype != rdt:
-            md = md.to(rdt)
-        mbat = MinibatchData(md.contiguous(), minibatch)
+        mbat = dataset(mask, False, real=True)
         it, Dout, xout = solve_cd_mask(ybat, Dd, alpha, xbat, tol, minibatch, maxiter,
                                        lasso_method, lasso_iter, lasso_tol, rng, kind, mbat)
     return it, _arrays.to_caller(Dout, kind), _arrays.to_caller(xout, kind)

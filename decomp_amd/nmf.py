@@ -51,6 +51,10 @@ def solve(y, D, x=None, tol=1.0e-3, minibatch=None, maxiter=1000, method='mu',
     mask (optional): [n_samples, n_channels], 0 marks a missing entry; float32 or
     float64, all arrays of the same dtype.  NumPy arrays (copied to the GPU, results
     returned as NumPy) or torch CUDA tensors (results returned as torch tensors).
+    Out of core (nmf.py:93-103): with a minibatch method, a torch CUDA ``D`` and NumPy
+    ``y`` / ``x`` / ``mask``, the NumPy arrays stay in pinned host memory and are streamed
+    through the GPU minibatch by minibatch (utils.data.AsyncMinibatchData); ``x`` then
+    comes back as a NumPy array.
 
     Returns (it, D, x) exactly as the reference: ``it`` is the iteration at which
     max|D - D_new| < tol was met, or ``maxiter`` when it never was.
@@ -68,17 +72,25 @@ def solve(y, D, x=None, tol=1.0e-3, minibatch=None, maxiter=1000, method='mu',
     assertion.assert_ndim('y', y, 2)
     assertion.assert_ndim('D', D, 2)
     assertion.assert_ndim('x', x, 2)
-    get_array_module(D, x_given)
+
+    if minibatch is None or kind == 'numpy':
+        get_array_module(D, x_given)
+    # out of core (nmf.py:93-103): device D, host data, minibatch method
+    streamed = (minibatch is not None and kind == 'torch' and
+                any(a is not None and not _arrays.is_torch(a) for a in (y, x_given, mask)))
 
     # ---- from here on everything lives on the GPU ----
     import torch
     D_dev = _arrays.to_device(D, copy=True)           # normalised in place below
     dev = D_dev.device.index
+    assertion.assert_nonnegative(D_dev)                               # nmf.py:64-65
+    if streamed:
+        return _solve_streamed(y, D_dev, x_given, tol, minibatch, maxiter, method, likelihood,
+                               mask, random_seed, kwargs)
     if x_given is None:
         x_dev = torch.ones(x.shape, dtype=D_dev.dtype, device=D_dev.device)
     else:
         x_dev = _arrays.to_device(x_given, dev, copy=True)   # updated in place
-    assertion.assert_nonnegative(D_dev)                               # nmf.py:64-65
     assertion.assert_nonnegative(x_dev)
     lik = None
     if likelihood in ['kl']:                                          # nmf.py:67-68
@@ -125,6 +137,50 @@ def solve(y, D, x=None, tol=1.0e-3, minibatch=None, maxiter=1000, method='mu',
         it, Dout, xout = nmf_minibatch.solve_kasai(ybat, D_dev, xbat, tol, minibatch, maxiter,
                                                    method, lik, mbat, rng, **kwargs)
     return it, _arrays.to_caller(Dout, kind), _arrays.to_caller(xout, kind)
+
+
+def _solve_streamed(y, D_dev, x_given, tol, minibatch, maxiter, method, likelihood, mask,
+                    random_seed, kwargs):
+    """nmf.py:93-111: every array that is a NumPy array stays on the host and is streamed
+    (x with write-back); device arrays use the in-core container.  Returns (it, D, x) with
+    x a NumPy array when it was streamed."""
+    import torch
+    from .utils.data import MinibatchData, AsyncMinibatchData, NoneIterator
+    from . import nmf_minibatch
+    if method not in MINIBATCH_METHODS:
+        raise NotImplementedError('NMF with {} algorithm is not yet '
+                                  'implemented.'.format(method))
+    dev = D_dev.device.index
+
+    def dataset(a, needs_update):
+        if a is None:
+            return NoneIterator()
+        if _arrays.is_torch(a):
+            t = _arrays.to_device(a, dev, copy=needs_update)
+            if needs_update:
+                assertion.assert_nonnegative(t)                       # nmf.py:65
+            return MinibatchData(t, minibatch)
+        if needs_update or likelihood in ['kl']:
+            assertion.assert_nonnegative_host_or_device(a)            # nmf.py:65,67-68
+        return AsyncMinibatchData(a, minibatch, needs_update=needs_update, device=dev)
+
+    if x_given is None:                                               # nmf.py:53-54: ones in D's module
+        x_given = torch.ones((y.shape[0], D_dev.shape[0]), dtype=D_dev.dtype, device=D_dev.device)
+    if _arrays.is_torch(y) and likelihood in ['kl']:
+        assertion.assert_nonnegative(_arrays.to_device(y, dev))
+    _arrays.l2_normalize_(D_dev, strict=True)                         # nmf.py:70
+    lik = _likelihood_code(likelihood)
+    xbat = dataset(x_given, True)
+    ybat = dataset(y, False)
+    mbat = dataset(mask, False)
+    rng = np.random.RandomState(random_seed)
+    if method in ['asg-mu', 'gsg-mu', 'asag-mu', 'gsag-mu']:
+        it, Dout, xout = nmf_minibatch.solve_serizel(ybat, D_dev, xbat, tol, minibatch, maxiter,
+                                                     method, lik, mbat, rng, **kwargs)
+    else:
+        it, Dout, xout = nmf_minibatch.solve_kasai(ybat, D_dev, xbat, tol, minibatch, maxiter,
+                                                   method, lik, mbat, rng, **kwargs)
+    return it, Dout, xout
 
 
 def _run_mu(y, mask, x, D, lik, tol, maxiter, resid_trace=None):

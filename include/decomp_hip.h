@@ -250,6 +250,18 @@ int dcp_lasso_admm_c128(dcp_handle* h, const void* Y, const double* mask, int ma
                         void* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
                         int positive, double rho, int* it_out);
 
+/* ---- row movers of the minibatch containers (decomp/utils/data.py:124-156, 214-313) ------ */
+/* gather : out[i, :] = in[index[i], :]      scatter: out[index[i], :] = in[i, :]      i < rows
+ * Rows are row_bytes long (any dtype); index: int64 in DEVICE memory.  `in` / `out` may be
+ * device memory or PINNED host memory (hipHostMalloc; mapped into the device's address space):
+ * the out-of-core container gathers each shuffled minibatch straight out of the host array over
+ * PCIe and scatters updated rows back, so no shuffle pass over the host data is ever needed.
+ * Asynchronous on the handle's stream. */
+int dcp_gather_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
+                          int64_t row_bytes, void* out);
+int dcp_scatter_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
+                           int64_t row_bytes, void* out);
+
 /* ---- online dictionary learning (block coordinate descent) -------------------------- */
 /* One minibatch step of decomp/dictionary_learning.py:135-164 (solve_cd), split at the
  * data-parallel exchange point like the NMF step:
