@@ -7,6 +7,7 @@
 
 #include "gemm_generic.hpp"
 #include "gemm_mfma_f32.hpp"
+#include "gemm_mfma_f64.hpp"
 #include "scalar.hpp"
 
 namespace dcp {
@@ -127,6 +128,13 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
     return TIER_SMALL;
 }
 
+// float64 products big enough for the 128 x 128 fp64 MFMA tile; smaller ones stay on the
+// generic 64 x 64 core (more workgroups for thin outputs).
+inline bool f64_on_mfma(int M, int N, int tile_sel) {
+    if (tile_sel == TILE_SMALL) return false;
+    return M >= 128 && N >= 128;
+}
+
 // Choose split-K so that the grid reaches ~target workgroups, each split a multiple
 // of 16 deep (the MFMA K block).  Returns the number of splits; sets a.klen.
 template <int FORM, class T>
@@ -142,6 +150,7 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_b
         if (FORM == FORM_TN) Mx *= 2; else Kx *= 2;
     }
     if (mfma) tier_dims(pick_tier<FORM>(Mx, Nx, Kx, a.tile, true), bm, bn);
+    if (std::is_same<T, double>::value && f64_on_mfma(a.M, a.N, a.tile)) { bm = F64Tile::BM; bn = F64Tile::BN; }
     const long tiles = (long)ceil_div(Mx, bm) * (ceil_div(n1, bn) + ceil_div(Nx - n1, bn));
     const long kblocks = ceil_div(Kx > 0 ? Kx : 1, 16);   // (real-extended depth for complex64)
     // splits allowed by the reduction depth: keep every split at least 512 deep (32 K blocks)
@@ -218,6 +227,20 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL>(stream, p, ce);
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
                 }
+            }
+        }
+        if constexpr (std::is_same<T, double>::value) {
+            if (f64_on_mfma(a.M, a.N, a.tile)) {
+                GemmProblemD p;
+                p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb;
+                p.B2 = a.B2; p.ldb2 = a.ldb2; p.n_b1 = a.n_b1;
+                p.M = a.M; p.N = a.N; p.K = a.K;
+                p.ksplits = a.ksplits; p.klen = a.klen;
+                p.tiles_m = p.tiles_n = 0;
+                p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
+                constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
+                constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
+                return launch_gemm_mfma_f64<AL, BL, Epi>(stream, p, epi);
             }
         }
         GenericProblem<T> p;

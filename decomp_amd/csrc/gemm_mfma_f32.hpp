@@ -57,9 +57,13 @@ struct GemmProblem {
     int mt_fast;   // 1: consecutive logical ids walk m tiles first
 };
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_>
+// PIPE_ = 1: the per-block barrier sits between the MFMA groups of a K block (operands of the
+// last group already in registers, first group of the next block prefetched right after the
+// barrier), so no wave leaves the barrier with nothing to feed the matrix pipe.
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int PIPE_ = 0>
 struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_;
+    static constexpr int PIPE = PIPE_;
     static constexpr int NWAVES = (BM_ / WM_) * (BN_ / WN_);
     static constexpr int NTHREADS = 64 * NWAVES;
 };
@@ -243,39 +247,111 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     }
     __syncthreads();
 
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int cur = kb & 1;
-        const float* sA = sA0 + cur * GA::ELEMS;
-        const float* sB = sB0 + cur * GB::ELEMS;
-        const bool more = (kb + 1) < nkb;
-        if (more) {  // issue next block's global loads; they land during the MFMAs
-            const int k0 = kbeg + (kb + 1) * BK;
-            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
-            panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
-        }
-#pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = panel_frag<ALAY, BM, BK>(sA, wm * WM + i * 32 + l31, c, h);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = panel_frag<BLAY, BN, BK>(sB, wn * WN + j * 32 + l31, c, h);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
+    if constexpr (Cfg::PIPE == 0) {
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int cur = kb & 1;
+            const float* sA = sA0 + cur * GA::ELEMS;
+            const float* sB = sB0 + cur * GB::ELEMS;
+            const bool more = (kb + 1) < nkb;
+            if (more) {  // issue next block's global loads; they land during the MFMAs
+                const int k0 = kbeg + (kb + 1) * BK;
+                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+                panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+            }
+    #pragma unroll
+            for (int c = 0; c < BK / 8; ++c) {
+                f32x4 fa[TM], fb[TN];
+    #pragma unroll
                 for (int i = 0; i < TM; ++i)
+                    fa[i] = panel_frag<ALAY, BM, BK>(sA, wm * WM + i * 32 + l31, c, h);
+    #pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = panel_frag<BLAY, BN, BK>(sB, wn * WN + j * 32 + l31, c, h);
+    #pragma unroll
+                for (int s = 0; s < 4; ++s)
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s],
+                                                                             acc[i][j], 0, 0, 0);
+            }
+            if (more) {
+                panel_lds_store<ALAY, BM, BK, NT>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
+                panel_lds_store<BLAY, BN, BK, NT>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
+            }
+            __syncthreads();
+        }
+    } else {
+        constexpr int NC = BK / 8;
+        static_assert(NC >= 2, "PIPE needs at least two MFMA groups per K block");
+        // Schedule per K block (registers ra/rb always hold the block AFTER the one in LDS):
+        //   groups 0 .. NC-2 : read the next group's operands, MFMA
+        //   last group       : publish block kb+1 (ra/rb -> other LDS buffer), barrier, start the
+        //                      global loads of block kb+2 (a whole K block of MFMAs to land),
+        //                      prefetch group 0 of block kb+1, MFMA with operands already held
+        f32x4 fa[TM], fb[TN];
+        if (nkb > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = panel_frag<ALAY, BM, BK>(sA0, wm * WM + i * 32 + l31, 0, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = panel_frag<BLAY, BN, BK>(sB0, wn * WN + j * 32 + l31, 0, h);
+        }
+        if (nkb > 1) {
+            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, kbeg + BK, kend, tid);
+            panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg + BK, kend, tid);
+        }
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int cur = kb & 1;
+            const float* sA = sA0 + cur * GA::ELEMS;
+            const float* sB = sB0 + cur * GB::ELEMS;
+            const bool more = (kb + 1) < nkb;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                f32x4 na[TM], nb[TN];
+                if (c + 1 < NC) {          // operands of the next group of THIS block
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        na[i] = panel_frag<ALAY, BM, BK>(sA, wm * WM + i * 32 + l31, c + 1, h);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s],
-                                                                         acc[i][j], 0, 0, 0);
+                        nb[j] = panel_frag<BLAY, BN, BK>(sB, wn * WN + j * 32 + l31, c + 1, h);
+                } else {
+                    if (more) {
+                        panel_lds_store<ALAY, BM, BK, NT>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
+                        panel_lds_store<BLAY, BN, BK, NT>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
+                    }
+                    __syncthreads();
+                    if ((kb + 2) < nkb) {
+                        const int k0 = kbeg + (kb + 2) * BK;
+                        panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+                        panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+                    }
+                    if (more) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            na[i] = panel_frag<ALAY, BM, BK>(sA0 + (cur ^ 1) * GA::ELEMS,
+                                                             wm * WM + i * 32 + l31, 0, h);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            nb[j] = panel_frag<BLAY, BN, BK>(sB0 + (cur ^ 1) * GB::ELEMS,
+                                                             wn * WN + j * 32 + l31, 0, h);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s],
+                                                                             acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = na[i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = nb[j];
+            }
         }
-        if (more) {
-            panel_lds_store<ALAY, BM, BK, NT>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
-            panel_lds_store<BLAY, BN, BK, NT>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
-        }
-        __syncthreads();
     }
 
     // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31,

@@ -65,6 +65,9 @@ typedef TileCfg<128, 128, 16, 32, 64, 2> Cfg8wT;         // 8: 8 waves, 32x64 pe
 typedef TileCfg<256, 128, 32, 64, 64, 1> Cfg8wBigDeep;   // 9: 8 waves, 256x128, BK = 32
 typedef TileCfg<256, 256, 32, 64, 64, 1> Cfg16wDeep;     // 10: 16 waves, 256x256, BK = 32 (128 KiB dynamic LDS)
 typedef TileCfg<256, 256, 32, 128, 64, 1> Cfg8wHuge;      // 11: 8 waves of 128x64, 256x256, BK = 32
+typedef TileCfg<256, 256, 16, 64, 64, 1, 1> Cfg16wPipe;    // 12: 16 waves, 256x256, barrier between MFMA groups
+typedef TileCfg<128, 128, 16, 64, 64, 2, 1> CfgLargePipe;  // 13: 4 waves, 128x128, same
+typedef TileCfg<256, 256, 32, 64, 64, 1, 1> Cfg16wDeepPipe; // 14: 16 waves, BK = 32, same
 
 template <class Cfg, int FORM, class Epi>
 hipError_t hook_cfg(hipStream_t st, const GemmArgs<float>& a, const Epi& epi) {
@@ -94,6 +97,9 @@ hipError_t gemm_hook_launch(hipStream_t st, const GemmArgs<T>& a, int tile, cons
             case 9: return hook_cfg<Cfg8wBigDeep, FORM>(st, a, epi);
             case 10: return hook_cfg<Cfg16wDeep, FORM>(st, a, epi);
             case 11: return hook_cfg<Cfg8wHuge, FORM>(st, a, epi);
+            case 12: return hook_cfg<Cfg16wPipe, FORM>(st, a, epi);
+            case 13: return hook_cfg<CfgLargePipe, FORM>(st, a, epi);
+            case 14: return hook_cfg<Cfg16wDeepPipe, FORM>(st, a, epi);
             default: break;
         }
     }

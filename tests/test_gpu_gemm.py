@@ -90,6 +90,22 @@ def test_f64_generic(form):
             assert err.max() < 1e-14, (form, M, N, K, ks, err.max())
 
 
+@pytest.mark.parametrize('form', [0, 1, 2])
+def test_f64_mfma(form):
+    """Outputs of at least 128 x 128 run on the fp64 MFMA core (v_mfma_f64_16x16x4_f64):
+    aligned shapes take the vector-load instantiation, ragged ones the bounds-checked one;
+    asymmetric operands catch any slip in the (f64-specific) C/D lane map."""
+    rng = np.random.RandomState(21 + form)
+    for (M, N, K) in SHAPES_ALIGNED + [(130, 258, 35), (257, 129, 4096), (300, 200, 100), (128, 640, 48)]:
+        for ks in (1, 3):
+            A, B = _operands(form, M, N, K, np.float64, rng)
+            C = gemm_hip(form, A, B, ksplits=ks)
+            err = np.abs(C - gemm_ref(form, A, B)) / gemm_bound(form, A, B)
+            assert err.max() < 1e-14, (form, M, N, K, ks, err.max())
+            Cg = gemm_hip(form, A, B, ksplits=ks, tile=2)       # generic VALU core
+            assert np.abs(C - Cg).max() <= 1e-13 * np.abs(Cg).max()
+
+
 def _cplx(rng, *s):
     return (rng.randn(*s) + 1j * rng.randn(*s)).astype(np.complex64)
 
