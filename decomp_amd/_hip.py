@@ -92,6 +92,8 @@ SIGNATURES = {
     'dcp_calib_read_f32': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_int, _c_vp]),
     'dcp_gemm_c64': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                               _c_int, _c_int]),
+    'dcp_gemm_c128': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
+                              _c_int, _c_int]),
     'dcp_nmf_mu_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                                 _c_int, _c_f32, _c_int, _P(_c_int), _P(_c_f32), _P(_c_f32)]),
     'dcp_nmf_mu_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,

@@ -179,7 +179,7 @@ struct AtomWs {
     T* rden = nullptr;   // [64]
     T* slabs = nullptr;  // split-K partials of G
     size_t slab_count = 0;
-    float* ext = nullptr;   // complex64: real extended images (max(4KF, 4*64*F) floats)
+    real_t<T>* ext = nullptr;   // complex: real extended images (max(4KF, 4*64*F) reals)
 };
 
 template <class T>
@@ -191,7 +191,7 @@ inline void atom_plan(WsPlan& p, int64_t F, int64_t K) {
     p.add<T>((size_t)kAtomBlkMax * kAtomBlkMax);
     p.add<T>((size_t)kAtomBlkMax);
     p.add<T>((size_t)64 * kAtomBlkMax * kAtomBlkMax);
-    if (std::is_same<T, c64>::value) p.add<float>((size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
+    if (scalar_traits<T>::is_complex) p.add<real_t<T> >((size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
 }
 
 template <class T>
@@ -204,8 +204,8 @@ inline int atom_carve(dcp_handle* h, AtomWs<T>& w, int64_t F, int64_t K) {
     w.rden = ws_alloc<T>(h, (size_t)kAtomBlkMax);
     w.slab_count = (size_t)64 * kAtomBlkMax * kAtomBlkMax;
     w.slabs = ws_alloc<T>(h, w.slab_count);
-    if (std::is_same<T, c64>::value) {
-        w.ext = ws_alloc<float>(h, (size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
+    if (scalar_traits<T>::is_complex) {
+        w.ext = ws_alloc<real_t<T> >(h, (size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
         if (!w.ext) return fail(h, DCP_ERR_INTERNAL, "atom sweep workspace plan");
     }
     if (!w.Ablk || !w.P || !w.G || !w.E || !w.Wl || !w.rden || !w.slabs)

@@ -33,9 +33,9 @@ struct GemmArgs {
     bool conjA = false, conjB = false;  // complex only
     int tile = TILE_AUTO;
     bool split_planned = false;  // set by plan_splits: tile tiers may count on split-K
-    // complex64 only: scratch for the real "extended" image of B (4 * rows(B) * cols(B) floats).
-    // With it NT / NN products run on the fp32 MFMA core; TN needs none.  Null -> generic core.
-    float* ext_ws = nullptr;
+    // complex only: scratch for the real "extended" image of B (4 * rows(B) * cols(B) reals).
+    // With it NT / NN products run on the fp32 / fp64 MFMA core; TN needs none.  Null -> generic core.
+    real_t<T>* ext_ws = nullptr;
 };
 
 // complex64 products on the fp32 MFMA core --------------------------------------------------
@@ -46,41 +46,41 @@ struct GemmArgs {
 //   TN, C = A^H B : real views of both operands, 2x2 blocks combined in the epilogue (mode 2)
 // i.e. the 4 real multiplies of every complex multiply, 8MNK flops, no operand copies except
 // the small ext(B).
-template <int TAG>   // a template only so that the header can be included in several TUs
-__global__ void __launch_bounds__(256) cplx_ext_kernel(const c64* __restrict__ B, long rows, long cols,
-                                                       long ld, float* __restrict__ out) {
+template <class R>
+__global__ void __launch_bounds__(256) cplx_ext_kernel(const cx<R>* __restrict__ B, long rows, long cols,
+                                                       long ld, R* __restrict__ out) {
     const long n = rows * cols;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
         const long r = i / cols, c = i - r * cols;
-        const c64 v = B[r * ld + c];
-        float* o0 = out + (2 * r) * (2 * cols) + 2 * c;
-        float* o1 = o0 + 2 * cols;
+        const cx<R> v = B[r * ld + c];
+        R* o0 = out + (2 * r) * (2 * cols) + 2 * c;
+        R* o1 = o0 + 2 * cols;
         o0[0] = v.re; o0[1] = v.im;
         o1[0] = -v.im; o1[1] = v.re;
     }
 }
 
-template <class E>
+template <class E, class R = float>
 struct CplxColEpi {   // kernel epilogue mode 1
     static constexpr int kMode = 1;
     E e;
-    __device__ __forceinline__ void pair(int r, int c, float re, float im, int s) const {
-        e(r, c, c64{re, im}, s);
+    __device__ __forceinline__ void pair(int r, int c, R re, R im, int s) const {
+        e(r, c, cx<R>{re, im}, s);
     }
-    __device__ __forceinline__ void operator()(int, int, float, int) const {}
+    __device__ __forceinline__ void operator()(int, int, R, int) const {}
 };
-template <class E>
+template <class E, class R = float>
 struct CplxTnEpi {    // kernel epilogue mode 2
     static constexpr int kMode = 2;
     E e;
-    __device__ __forceinline__ void pair(int r, int c, float re, float im, int s) const {
-        e(r, c, c64{re, im}, s);
+    __device__ __forceinline__ void pair(int r, int c, R re, R im, int s) const {
+        e(r, c, cx<R>{re, im}, s);
     }
-    __device__ __forceinline__ void operator()(int, int, float, int) const {}
+    __device__ __forceinline__ void operator()(int, int, R, int) const {}
 };
 
 template <int FORM>
-inline bool cplx_on_mfma(bool conjA, bool conjB, const float* ext_ws) {
+inline bool cplx_on_mfma(bool conjA, bool conjB, const void* ext_ws) {
     if (FORM == FORM_TN) return conjA && !conjB;
     if (FORM == FORM_NT) return conjB && !conjA && ext_ws != nullptr;
     return !conjA && !conjB && ext_ws != nullptr;
@@ -151,6 +151,14 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_b
     }
     if (mfma) tier_dims(pick_tier<FORM>(Mx, Nx, Kx, a.tile, true), bm, bn);
     if (std::is_same<T, double>::value && f64_on_mfma(a.M, a.N, a.tile)) { bm = F64Tile::BM; bn = F64Tile::BN; }
+    if (std::is_same<T, c128>::value && cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws)) {
+        const int Me = (FORM == FORM_TN) ? 2 * a.M : a.M;
+        if (f64_on_mfma(Me, 2 * a.N, a.tile)) {      // real-extended problem on the fp64 MFMA core
+            Mx = Me; Nx = 2 * a.N; n1 *= 2;
+            if (FORM != FORM_TN) Kx *= 2;
+            bm = F64Tile::BM; bn = F64Tile::BN;
+        }
+    }
     const long tiles = (long)ceil_div(Mx, bm) * (ceil_div(n1, bn) + ceil_div(Nx - n1, bn));
     const long kblocks = ceil_div(Kx > 0 ? Kx : 1, 16);   // (real-extended depth for complex64)
     // splits allowed by the reduction depth: keep every split at least 512 deep (32 K blocks)
@@ -216,8 +224,8 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     long g = (rowsB * colsB + 255) / 256;
                     if (g > 4096) g = 4096;
                     if (g < 1) g = 1;
-                    hipLaunchKernelGGL((cplx_ext_kernel<0>), dim3((unsigned)g), dim3(256), 0, stream, a.B, rowsB,
-                                       colsB, a.ldb, a.ext_ws);
+                    hipLaunchKernelGGL((cplx_ext_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, a.B,
+                                       rowsB, colsB, a.ldb, a.ext_ws);
                     p.B = a.ext_ws; p.ldb = 2 * colsB;
                     p.M = a.M; p.N = 2 * a.N; p.K = 2 * a.K;
                     if (a.ksplits <= 1) p.klen = 0;
@@ -226,6 +234,43 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
                     if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL>(stream, p, ce);
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
+                }
+            }
+        }
+        if constexpr (std::is_same<T, c128>::value) {
+            const int Me = (FORM == FORM_TN) ? 2 * a.M : a.M;
+            if (cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws) && f64_on_mfma(Me, 2 * a.N, a.tile)) {
+                // complex128 on the fp64 MFMA core: same real-extended formulation as complex64
+                GemmProblemD p;
+                p.A = reinterpret_cast<const double*>(a.A); p.lda = 2 * a.lda;
+                p.B2 = nullptr; p.ldb2 = 0; p.n_b1 = 2 * a.N;
+                p.ksplits = a.ksplits; p.klen = a.klen;
+                p.tiles_m = p.tiles_n = 0;
+                p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
+                constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
+                constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
+                if constexpr (FORM == FORM_TN) {
+                    p.B = reinterpret_cast<const double*>(a.B); p.ldb = 2 * a.ldb;
+                    if (a.B2 != nullptr) {
+                        p.B2 = reinterpret_cast<const double*>(a.B2); p.ldb2 = 2 * a.ldb2;
+                        p.n_b1 = 2 * a.n_b1;
+                    }
+                    p.M = 2 * a.M; p.N = 2 * a.N; p.K = a.K;
+                    CplxTnEpi<Epi, double> ce{epi};
+                    return launch_gemm_mfma_f64<AL, BL>(stream, p, ce);
+                } else {
+                    const long rowsB = (FORM == FORM_NT) ? a.N : a.K;
+                    const long colsB = (FORM == FORM_NT) ? a.K : a.N;
+                    long g = (rowsB * colsB + 255) / 256;
+                    if (g > 4096) g = 4096;
+                    if (g < 1) g = 1;
+                    hipLaunchKernelGGL((cplx_ext_kernel<double>), dim3((unsigned)g), dim3(256), 0, stream, a.B,
+                                       rowsB, colsB, a.ldb, a.ext_ws);
+                    p.B = a.ext_ws; p.ldb = 2 * colsB;
+                    p.M = a.M; p.N = 2 * a.N; p.K = 2 * a.K;
+                    if (a.ksplits <= 1) p.klen = 0;
+                    CplxColEpi<Epi, double> ce{epi};
+                    return launch_gemm_mfma_f64<AL, BL>(stream, p, ce);
                 }
             }
         }

@@ -233,7 +233,12 @@ __global__ void __launch_bounds__(F64Tile::NT, 2) gemm_mfma_f64_kernel(GemmProbl
         __syncthreads();
     }
 
-    // C layout of the 16x16 f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+    // C layout of the 16x16 f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg.
+    // Epi::kMode as in the fp32 core: 0 real; 1 complex product on real-extended operands, the
+    // (re, im) of an output sit in lanes 2q / 2q+1; 2 complex x^H y on the real views of both
+    // operands, the 2x2 block (rr ri; ir ii) sits in lanes (g, 2q), (g, 2q+1), (g+1, 2q),
+    // (g+1, 2q+1) of one register: re = rr + ii, im = ri - ir.
+    constexpr int MODE = epi_mode<Epi>::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -242,7 +247,20 @@ __global__ void __launch_bounds__(F64Tile::NT, 2) gemm_mfma_f64_kernel(GemmProbl
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * WM + i * 16 + g + 4 * r;
-                if (!EDGE || (row < p.M && col < ncol_end)) epi(row, col, acc[i][j][r], split);
+                const double v = acc[i][j][r];
+                if constexpr (MODE == 0) {
+                    if (!EDGE || (row < p.M && col < ncol_end)) epi(row, col, v, split);
+                } else if constexpr (MODE == 1) {
+                    const double o = __shfl_xor(v, 1, 64);          // executed by every lane
+                    if (!(lane & 1) && (!EDGE || (row < p.M && col < ncol_end)))
+                        epi.pair(row, col >> 1, v, o, split);
+                } else {
+                    const double ii = __shfl_xor(v, 17, 64);
+                    const double ri = __shfl_xor(v, 1, 64);
+                    const double ir = __shfl_xor(v, 16, 64);
+                    if (!(lane & 1) && !(g & 1) && (!EDGE || (row < p.M && col < ncol_end)))
+                        epi.pair(row >> 1, col >> 1, v + ii, ri - ir, split);
+                }
             }
         }
     }

@@ -376,8 +376,8 @@ struct LassoWs {
     work_t<T>* inv_a = nullptr;  // admm: K x K work matrices (ping-pong) or the [N,K,K] per-row systems
     work_t<T>* inv_b = nullptr;
     R* gpart = nullptr;  // [64, K] Gershgorin column-sum stripes
-    float* ext1 = nullptr;  // complex64: real extended image of a [K,F] operand (4KF floats)
-    float* ext2 = nullptr;  // complex64: real extended image of AAt (4K^2 floats)
+    R* ext1 = nullptr;   // complex: real extended image of a [K,F] operand (4KF reals)
+    R* ext2 = nullptr;   // complex: real extended image of AAt (4K^2 reals)
     int* flag = nullptr;
     size_t slab_count = 0;
 };
@@ -410,9 +410,9 @@ inline void lasso_plan(WsPlan& p, int64_t N, int64_t F, int64_t K, int mask_ndim
     p.add<R>(4);
     p.add<R>((size_t)64 * K);
     p.add<int>(4);
-    if (std::is_same<T, c64>::value) {
-        p.add<float>((size_t)4 * K * F);
-        p.add<float>((size_t)4 * K * K);
+    if (scalar_traits<T>::is_complex) {
+        p.add<R>((size_t)4 * K * F);
+        p.add<R>((size_t)4 * K * K);
     }
 }
 
@@ -451,9 +451,9 @@ inline int lasso_carve(dcp_handle* h, LassoWs<T>& w, int64_t N, int64_t F, int64
     w.scal = ws_alloc<R>(h, 4);
     w.gpart = ws_alloc<R>(h, (size_t)64 * K);
     w.flag = ws_alloc<int>(h, 4);
-    if (std::is_same<T, c64>::value) {
-        w.ext1 = ws_alloc<float>(h, (size_t)4 * K * F);
-        w.ext2 = ws_alloc<float>(h, (size_t)4 * K * K);
+    if (scalar_traits<T>::is_complex) {
+        w.ext1 = ws_alloc<R>(h, (size_t)4 * K * F);
+        w.ext2 = ws_alloc<R>(h, (size_t)4 * K * K);
         if (!w.ext1 || !w.ext2) return fail(h, DCP_ERR_INTERNAL, "lasso workspace plan mismatch");
     }
     if (!w.An || !w.yAt || !w.AAt || !w.slabs || !w.xb[3] || !w.s || !w.alphak || !w.tolk ||

@@ -122,8 +122,9 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
         a.conjB = (form == FORM_NT);
         a.conjA = (form == FORM_TN);
     }
-    float* ext = nullptr;
-    const size_t ext_floats = std::is_same<T, c64>::value ? (size_t)4 * N * K : 0;
+    typedef real_t<T> RT;
+    RT* ext = nullptr;
+    const size_t ext_floats = scalar_traits<T>::is_complex ? (size_t)4 * N * K : 0;
     a.tile = (tile >= 3) ? TILE_LARGE : tile;   // hook-only shapes plan splits as 128x128
     hipError_t e = hipSuccess;
     if (ksplits > 1) {
@@ -133,11 +134,11 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
         a.ksplits = (int)((K + a.klen - 1) / a.klen);
         WsPlan plan;
         plan.add<T>((size_t)a.ksplits * M * N);
-        plan.add<float>(ext_floats + 4);
+        plan.add<RT>(ext_floats + 4);
         DCP_TRY(ws_reserve(h, plan.total));
         ws_reset(h);
         T* slabs = ws_alloc<T>(h, (size_t)a.ksplits * M * N);
-        ext = ws_alloc<float>(h, ext_floats + 4);
+        ext = ws_alloc<RT>(h, ext_floats + 4);
         if (!slabs || !ext) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
         if (ext_floats) {
             a.ext_ws = ext;
@@ -159,10 +160,10 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
     } else {
         if (ext_floats) {
             WsPlan plan;
-            plan.add<float>(ext_floats + 4);
+            plan.add<RT>(ext_floats + 4);
             DCP_TRY(ws_reserve(h, plan.total));
             ws_reset(h);
-            ext = ws_alloc<float>(h, ext_floats + 4);
+            ext = ws_alloc<RT>(h, ext_floats + 4);
             if (!ext) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
             a.ext_ws = ext;
         }
@@ -462,6 +463,11 @@ int dcp_gemm_c64(dcp_handle* h, int form, const void* A, const void* B, void* C,
                  int64_t K, int ksplits, int tile) {
     return gemm_api<c64>(h, form, reinterpret_cast<const c64*>(A), reinterpret_cast<const c64*>(B),
                          reinterpret_cast<c64*>(C), M, N, K, ksplits, tile);
+}
+int dcp_gemm_c128(dcp_handle* h, int form, const void* A, const void* B, void* C, int64_t M, int64_t N,
+                  int64_t K, int ksplits, int tile) {
+    return gemm_api<c128>(h, form, reinterpret_cast<const c128*>(A), reinterpret_cast<const c128*>(B),
+                          reinterpret_cast<c128*>(C), M, N, K, ksplits, tile);
 }
 
 int dcp_gather_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,

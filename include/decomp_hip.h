@@ -107,6 +107,8 @@ int dcp_gemm_f64(dcp_handle* h, int form, const double* A, const double* B, doub
 /* complex64: form 0 = A B^H, 1 = A B, 2 = A^H B (the conjugations the solvers use) */
 int dcp_gemm_c64(dcp_handle* h, int form, const void* A, const void* B, void* C,
                  int64_t M, int64_t N, int64_t K, int ksplits, int tile);
+int dcp_gemm_c128(dcp_handle* h, int form, const void* A, const void* B, void* C,
+                  int64_t M, int64_t N, int64_t K, int ksplits, int tile);
 
 /* PMC calibration aid (not a reference interface): reads p[rows, cols] exactly once with the
  * global-load shape of the GEMM panel loaders (pattern 0: 16 rows x 64 B per wave instruction;

@@ -133,3 +133,32 @@ def test_c64_on_mfma(form):
             C = gemm_hip(form, A, B, ksplits=ks, tile=tile)
             err = np.abs(C - ref) / bound
             assert err.max() < 2e-5, (form, M, N, K, ks, tile, err.max())
+
+
+@pytest.mark.parametrize('form', [0, 1, 2])
+def test_c128_on_mfma(form):
+    """complex128 products whose real-extended output is at least 128 x 128 run on the fp64 MFMA
+    core (real extended operands; lane-pair / lane-quad recombination in the epilogue); tile=2
+    forces the generic complex core for comparison."""
+    rng = np.random.RandomState(50 + form)
+
+    def cplx(*s):
+        return rng.randn(*s) + 1j * rng.randn(*s)
+    for (M, N, K, ks) in [(256, 256, 128, 1), (128, 64, 512, 4), (130, 70, 35, 1), (64, 96, 1000, 7),
+                          (512, 128, 256, 1), (300, 129, 77, 3)]:
+        if form == 0:
+            A, B = cplx(M, K), cplx(N, K)
+            ref = A @ B.conj().T
+            bound = np.abs(A) @ np.abs(B).T
+        elif form == 1:
+            A, B = cplx(M, K), cplx(K, N)
+            ref = A @ B
+            bound = np.abs(A) @ np.abs(B)
+        else:
+            A, B = cplx(K, M), cplx(K, N)
+            ref = A.conj().T @ B
+            bound = np.abs(A).T @ np.abs(B)
+        for tile in (0, 2):
+            C = gemm_hip(form, A, B, ksplits=ks, tile=tile)
+            err = np.abs(C - ref) / bound
+            assert err.max() < 1e-14, (form, M, N, K, ks, tile, err.max())

@@ -66,5 +66,31 @@ def main():
           % (N, F, K, ms, W / ms / 1e9, W / ms / 1e9 / 78.6 * 100))
 
 
+def complex128_lasso():
+    """dictionary-learning-like LASSO call in complex128 (the reference's default complex dtype)."""
+    import time
+    import numpy as np
+    from decomp_amd import lasso
+    N, F, K = 8192, 2048, 256
+    g = torch.Generator(device='cuda')
+    g.manual_seed(3)
+
+    def randn(*s):
+        return torch.complex(torch.randn(s, generator=g, device='cuda', dtype=torch.float64),
+                             torch.randn(s, generator=g, device='cuda', dtype=torch.float64))
+    A = randn(K, F)
+    xt = randn(N, K) * (torch.rand((N, K), generator=g, device='cuda') < 0.05)
+    y = xt @ A + 0.1 * randn(N, F)
+    lasso.solve(y, A, 0.05, tol=1e-12, method='ista', maxiter=3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    it, x = lasso.solve(y, A, 0.05, tol=1e-12, method='ista', maxiter=30)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flops = 8.0 * N * F * K + 8.0 * K * K * F + 30 * 8.0 * N * K * K
+    print('lasso ista c128 %dx%d k=%d, 30 iterations: %.2f ms  %.1f real TFLOP/s' % (N, F, K, dt * 1e3, flops / dt / 1e12))
+
+
 if __name__ == '__main__':
     main()
+    complex128_lasso()
