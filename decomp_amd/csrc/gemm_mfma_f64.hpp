@@ -10,10 +10,9 @@
 // a 4x4 register-tiled v_fma_f64 loop).  Lane l: A[row l&15][k l>>4], B[k l>>4][col l&15];
 // C/D: col = l&15, row = (l>>4) + 4*reg (NOT the f32 map, guide cdna_hip_programming.md).
 //
-// Workgroup: 128 x 128 tile, BK = 16, 512 threads = 8 waves, each wave 32 (m) x 64 (n) =
-// 2 x 4 accumulators (64 VGPRs).  64 KiB LDS (two panels, double buffered) -> two workgroups
-// per CU, 4 waves per SIMD.  Staging as in the fp32 core: global -> registers -> LDS, one
-// barrier per K block.
+// Workgroup: 128 x 128 tile, BK = 16, 1024 threads = 16 waves, each wave 32 x 32 = 2 x 2
+// accumulators (32 VGPRs).  64 KiB LDS (two panels, double buffered).  Staging as in the fp32
+// core: global -> registers -> LDS, one barrier per K block.
 //
 // LDS images:
 //   KMAJOR panel: [rows][16] doubles, 16-byte chunks XOR-swizzled (chunk q of row r at
@@ -48,34 +47,40 @@ struct GemmProblemD {
     int mt_fast;
 };
 
-struct F64Tile {
-    static constexpr int BM = 128, BN = 128, BK = 16, WM = 32, WN = 64;
+template <int BM_, int BN_, int WM_, int WN_, int MINW_>
+struct F64Cfg {
+    static constexpr int BM = BM_, BN = BN_, BK = 16, WM = WM_, WN = WN_, MINW = MINW_;
     static constexpr int NWAVES = (BM / WM) * (BN / WN);
-    static constexpr int NT = 64 * NWAVES;   // 512
+    static constexpr int NT = 64 * NWAVES;
     static constexpr int XPAD = 16;
 };
+// The production tile: 16 waves of 32 x 32 (measured on Y.D^T, 32768x256x4096: 64.4 TF = 82 % of
+// the fp64 peak; 8 waves of 32 x 64: 55.9; 4 waves of 64 x 64: 59.2; 128 x 256 / 16 waves: 64.7 --
+// tools/bench_f64.py).  One workgroup already puts 4 waves on every SIMD, so thin problems with
+// one tile per CU keep the matrix pipe fed.
+typedef F64Cfg<128, 128, 32, 32, 1> F64Tile;
 
-template <int LAY, int ROWS>
+template <int LAY, int ROWS, int NT_ = F64Tile::NT>
 struct PanelD {
-    static constexpr int BK = F64Tile::BK;
-    static constexpr int XSTRIDE = ROWS + F64Tile::XPAD;
+    static constexpr int BK = 16;
+    static constexpr int XSTRIDE = ROWS + 16;
     static constexpr int ELEMS = (LAY == KMAJOR) ? ROWS * BK : BK * XSTRIDE;
-    static constexpr int CH = ROWS * BK / 2 / F64Tile::NT;   // 16-byte chunks per thread per block
-    static_assert(ROWS * BK % (2 * F64Tile::NT) == 0, "panel must be whole chunks per thread");
+    static constexpr int CH = ROWS * BK / 2 / NT_;   // 16-byte chunks per thread per block
+    static_assert(ROWS * BK % (2 * NT_) == 0, "panel must be whole chunks per thread");
     // double offset of 16-byte chunk q (2 doubles) of row r in the swizzled KMAJOR image
     __device__ static __forceinline__ int kchunk(int r, int q) {
         return r * BK + ((q ^ ((r >> 1) & 7)) << 1);
     }
 };
 
-template <int LAY, int ROWS, bool EDGE, int CH>
+template <int LAY, int ROWS, bool EDGE, int NT_, int CH>
 __device__ __forceinline__ void panel_gload_d(f64x2 (&r)[CH], const double* __restrict__ p, long ld,
                                               int row0, int nrows, int k0, int kend, int tid) {
-    static_assert(CH == PanelD<LAY, ROWS>::CH, "register panel size");
-    constexpr int BK = F64Tile::BK;
+    static_assert(CH == PanelD<LAY, ROWS, NT_>::CH, "register panel size");
+    constexpr int BK = 16;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int idx = tid + i * F64Tile::NT;
+        const int idx = tid + i * NT_;
         if (LAY == KMAJOR) {
             const int row = idx / (BK / 2), kq = (idx % (BK / 2)) * 2;
             const double* src = p + (long)(row0 + row) * ld + (k0 + kq);
@@ -100,13 +105,13 @@ __device__ __forceinline__ void panel_gload_d(f64x2 (&r)[CH], const double* __re
     }
 }
 
-template <int LAY, int ROWS, int CH>
+template <int LAY, int ROWS, int NT_, int CH>
 __device__ __forceinline__ void panel_lds_store_d(double* s, const f64x2 (&r)[CH], int tid) {
-    static_assert(CH == PanelD<LAY, ROWS>::CH, "register panel size");
-    constexpr int BK = F64Tile::BK;
+    static_assert(CH == PanelD<LAY, ROWS, NT_>::CH, "register panel size");
+    constexpr int BK = 16;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int idx = tid + i * F64Tile::NT;
+        const int idx = tid + i * NT_;
         if (LAY == KMAJOR) {
             const int row = idx / (BK / 2), q = idx % (BK / 2);
             *reinterpret_cast<f64x2*>(s + PanelD<LAY, ROWS>::kchunk(row, q)) = r[i];
@@ -131,14 +136,15 @@ __device__ __forceinline__ f64x2 panel_frag_d(const double* s, int row, int c, i
     }
 }
 
-template <int ALAY, int BLAY, bool EDGE, class Epi>
-__global__ void __launch_bounds__(F64Tile::NT, 2) gemm_mfma_f64_kernel(GemmProblemD p, Epi epi) {
-    constexpr int BM = F64Tile::BM, BN = F64Tile::BN, BK = F64Tile::BK;
-    constexpr int WM = F64Tile::WM, WN = F64Tile::WN;
+template <class Cfg, int ALAY, int BLAY, bool EDGE, class Epi>
+__global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) gemm_mfma_f64_kernel(GemmProblemD p, Epi epi) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+    constexpr int WM = Cfg::WM, WN = Cfg::WN;
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int WAVES_N = BN / WN;
-    typedef PanelD<ALAY, BM> GA;
-    typedef PanelD<BLAY, BN> GB;
+    constexpr int NT = Cfg::NT;
+    typedef PanelD<ALAY, BM, NT> GA;
+    typedef PanelD<BLAY, BN, NT> GB;
     // panels above the 64 KiB static limit (XMAJOR pads) use dynamic LDS, raised by the launcher
     constexpr int LDS_DOUBLES = 2 * (GA::ELEMS + GB::ELEMS);
     constexpr bool DYN = (LDS_DOUBLES * 8 > 65536);
@@ -193,10 +199,10 @@ __global__ void __launch_bounds__(F64Tile::NT, 2) gemm_mfma_f64_kernel(GemmProbl
     f64x2 ra[GA::CH], rb[GB::CH];
     const int nkb = (kend - kbeg + BK - 1) / BK;
     if (nkb > 0) {
-        panel_gload_d<ALAY, BM, EDGE>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
-        panel_gload_d<BLAY, BN, EDGE>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
-        panel_lds_store_d<ALAY, BM>(sA0, ra, tid);
-        panel_lds_store_d<BLAY, BN>(sB0, rb, tid);
+        panel_gload_d<ALAY, BM, EDGE, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+        panel_gload_d<BLAY, BN, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
+        panel_lds_store_d<ALAY, BM, NT>(sA0, ra, tid);
+        panel_lds_store_d<BLAY, BN, NT>(sB0, rb, tid);
     }
     __syncthreads();
 
@@ -207,8 +213,8 @@ __global__ void __launch_bounds__(F64Tile::NT, 2) gemm_mfma_f64_kernel(GemmProbl
         const bool more = (kb + 1) < nkb;
         if (more) {
             const int k0 = kbeg + (kb + 1) * BK;
-            panel_gload_d<ALAY, BM, EDGE>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
-            panel_gload_d<BLAY, BN, EDGE>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+            panel_gload_d<ALAY, BM, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+            panel_gload_d<BLAY, BN, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
         }
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
@@ -227,8 +233,8 @@ __global__ void __launch_bounds__(F64Tile::NT, 2) gemm_mfma_f64_kernel(GemmProbl
                                                                          0, 0, 0);
         }
         if (more) {
-            panel_lds_store_d<ALAY, BM>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
-            panel_lds_store_d<BLAY, BN>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
+            panel_lds_store_d<ALAY, BM, NT>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
+            panel_lds_store_d<BLAY, BN, NT>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
         }
         __syncthreads();
     }
@@ -266,9 +272,9 @@ __global__ void __launch_bounds__(F64Tile::NT, 2) gemm_mfma_f64_kernel(GemmProbl
     }
 }
 
-template <int ALAY, int BLAY, class Epi>
-inline hipError_t launch_gemm_mfma_f64(hipStream_t stream, GemmProblemD p, const Epi& epi) {
-    constexpr int BM = F64Tile::BM, BN = F64Tile::BN, BK = F64Tile::BK;
+template <class Cfg, int ALAY, int BLAY, class Epi>
+inline hipError_t launch_gemm_mfma_f64_cfg(hipStream_t stream, GemmProblemD p, const Epi& epi) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
     if (p.B2 == nullptr) p.n_b1 = p.N;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n1 = (p.n_b1 + BN - 1) / BN;
@@ -284,26 +290,31 @@ inline hipError_t launch_gemm_mfma_f64(hipStream_t stream, GemmProblemD p, const
     if (p.B2 != nullptr) fast = fast && (p.n_b1 % BN == 0) && (p.ldb2 % 2 == 0) && al16(p.B2);
     const int grid = p.tiles_m * p.tiles_n * p.ksplits;
     if (grid <= 0) return hipSuccess;
-    constexpr int lds_bytes = 16 * (PanelD<ALAY, BM>::ELEMS + PanelD<BLAY, BN>::ELEMS);
+    constexpr int lds_bytes = 16 * (PanelD<ALAY, BM, Cfg::NT>::ELEMS + PanelD<BLAY, BN, Cfg::NT>::ELEMS);
     constexpr int dyn_bytes = lds_bytes > 65536 ? lds_bytes : 0;
     if (dyn_bytes) {
         static bool raised_fast = false, raised_edge = false;   // per instantiation
         bool& raised = fast ? raised_fast : raised_edge;
         if (!raised) {
-            const void* fn = fast ? reinterpret_cast<const void*>(&gemm_mfma_f64_kernel<ALAY, BLAY, false, Epi>)
-                                  : reinterpret_cast<const void*>(&gemm_mfma_f64_kernel<ALAY, BLAY, true, Epi>);
+            const void* fn = fast ? reinterpret_cast<const void*>(&gemm_mfma_f64_kernel<Cfg, ALAY, BLAY, false, Epi>)
+                                  : reinterpret_cast<const void*>(&gemm_mfma_f64_kernel<Cfg, ALAY, BLAY, true, Epi>);
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dyn_bytes);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
     if (fast)
-        hipLaunchKernelGGL((gemm_mfma_f64_kernel<ALAY, BLAY, false, Epi>), dim3(grid), dim3(F64Tile::NT),
+        hipLaunchKernelGGL((gemm_mfma_f64_kernel<Cfg, ALAY, BLAY, false, Epi>), dim3(grid), dim3(Cfg::NT),
                            dyn_bytes, stream, p, epi);
     else
-        hipLaunchKernelGGL((gemm_mfma_f64_kernel<ALAY, BLAY, true, Epi>), dim3(grid), dim3(F64Tile::NT),
+        hipLaunchKernelGGL((gemm_mfma_f64_kernel<Cfg, ALAY, BLAY, true, Epi>), dim3(grid), dim3(Cfg::NT),
                            dyn_bytes, stream, p, epi);
     return hipGetLastError();
+}
+
+template <int ALAY, int BLAY, class Epi>
+inline hipError_t launch_gemm_mfma_f64(hipStream_t stream, GemmProblemD p, const Epi& epi) {
+    return launch_gemm_mfma_f64_cfg<F64Tile, ALAY, BLAY, Epi>(stream, p, epi);
 }
 
 }  // namespace dcp

@@ -82,8 +82,35 @@ hipError_t hook_cfg(hipStream_t st, const GemmArgs<float>& a, const Epi& epi) {
     return launch_gemm_mfma<Cfg, AL, BL, Epi>(st, p, epi);
 }
 
+// fp64 tile experiments (test hook only): codes 3..6
+typedef F64Cfg<256, 128, 32, 64, 1> F64Big;      // 3: 16 waves, 256 x 128
+typedef F64Cfg<128, 128, 64, 64, 1> F64Fat;      // 4: 4 waves of 64 x 64 (128 accumulator registers)
+typedef F64Cfg<128, 256, 32, 64, 1> F64Wide;     // 5: 16 waves, 128 x 256
+typedef F64Cfg<128, 128, 32, 64, 2> F64Thin;     // 6: 8 waves of 32 x 64, two workgroups / CU
+
+template <int FORM, class Epi>
+hipError_t gemm_hook_launch_f64(hipStream_t st, const GemmArgs<double>& a, int tile, const Epi& epi) {
+    if (tile >= 3 && tile <= 6) {
+        GemmProblemD p;
+        p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb;
+        p.B2 = nullptr; p.ldb2 = 0; p.n_b1 = a.N;
+        p.M = a.M; p.N = a.N; p.K = a.K;
+        p.ksplits = a.ksplits; p.klen = a.klen;
+        p.tiles_m = p.tiles_n = 0;
+        p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
+        constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
+        constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
+        if (tile == 3) return launch_gemm_mfma_f64_cfg<F64Big, AL, BL, Epi>(st, p, epi);
+        if (tile == 4) return launch_gemm_mfma_f64_cfg<F64Fat, AL, BL, Epi>(st, p, epi);
+        if (tile == 5) return launch_gemm_mfma_f64_cfg<F64Wide, AL, BL, Epi>(st, p, epi);
+        return launch_gemm_mfma_f64_cfg<F64Thin, AL, BL, Epi>(st, p, epi);
+    }
+    return gemm<FORM>(st, a, epi);
+}
+
 template <int FORM, class T, class Epi>
 hipError_t gemm_hook_launch(hipStream_t st, const GemmArgs<T>& a, int tile, const Epi& epi) {
+    if constexpr (std::is_same<T, double>::value) return gemm_hook_launch_f64<FORM>(st, a, tile, epi);
     if constexpr (std::is_same<T, float>::value) {
         switch (tile) {
             case 3:

@@ -43,13 +43,14 @@ def main():
     C = torch.empty((N, K), device='cuda', dtype=dd)
     for form, (A, B, M_, N_, K_) in {0: (Y, D0, N, K, F), 2: (xt, Y, K, F, N)}.items():
         out = torch.empty((M_, N_), device='cuda', dtype=dd)
-        for splits in ((1,) if form == 0 else (1, 16)):
-            ms = timed(lambda: _hip.check(h, lib.dcp_gemm_f64(h, form, _arrays.ptr(A), _arrays.ptr(B),
-                                                               _arrays.ptr(out), M_, N_, K_, splits, 0),
-                                          'gemm'), 5)
-            print('gemm f64 form %d  %dx%dx%d splits %2d: %.3f ms  %.1f TFLOP/s (%.0f %% of 78.6)'
-                  % (form, M_, N_, K_, splits, ms, 2.0 * M_ * N_ * K_ / ms / 1e9,
-                     2.0 * M_ * N_ * K_ / ms / 1e9 / 78.6 * 100))
+        for splits in ((1,) if form == 0 else (16,)):
+            for tile in (0, 3, 4, 5, 6, 2):
+                ms = timed(lambda: _hip.check(h, lib.dcp_gemm_f64(h, form, _arrays.ptr(A), _arrays.ptr(B),
+                                                                   _arrays.ptr(out), M_, N_, K_, splits, tile),
+                                              'gemm'), 5)
+                print('gemm f64 form %d  %dx%dx%d splits %2d tile %d: %.3f ms  %.1f TFLOP/s (%.0f %% of 78.6)'
+                      % (form, M_, N_, K_, splits, tile, ms, 2.0 * M_ * N_ * K_ / ms / 1e9,
+                         2.0 * M_ * N_ * K_ / ms / 1e9 / 78.6 * 100))
     D = D0.clone()
     _arrays.l2_normalize_(D, strict=True)
     x = torch.ones((N, K), device='cuda', dtype=dd)
