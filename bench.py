@@ -75,9 +75,18 @@ def cpu_baseline(budget_s=20.0):
     import numpy as np
     from oracle import nmf as onmf, common
     try:
-        cores = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
+        affinity = os.cpu_count() or 1
+    cores, blas = affinity, 'unknown'
+    try:    # the threads the BLAS behind NumPy really runs (what `cores` must state)
+        from threadpoolctl import threadpool_info
+        pools = [p for p in threadpool_info() if p.get('user_api') == 'blas']
+        if pools:
+            cores = int(max(p.get('num_threads', 1) for p in pools))
+            blas = '%s %s' % (pools[0].get('internal_api'), pools[0].get('version'))
+    except Exception:
+        pass
     rows = 4096
     rng = np.random.RandomState(0)
     Dt = np.maximum(rng.randn(N_ATOMS, N_FEAT), 0).astype(np.float32)
@@ -88,15 +97,98 @@ def cpu_baseline(budget_s=20.0):
     x, D, _ = onmf.mu_step(y, x, D)           # warm-up (BLAS threads, page faults)
     t0 = time.perf_counter()
     iters = 0
-    while iters < 3 or (time.perf_counter() - t0 < budget_s and iters < 40):
+    while iters < 3 or (time.perf_counter() - t0 < budget_s and iters < 400):
         x, D, _ = onmf.mu_step(y, x, D)
         iters += 1
     per_iter = (time.perf_counter() - t0) / iters
     scale = N_ROWS / rows
     return {'value': 1.0 / (per_iter * scale), 'unit': 'iterations/s', 'cores': cores,
-            'kind': 'port',
+            'kind': 'port', 'blas': blas, 'affinity_cores': affinity,
             'sample': 'oracle.nmf.mu_step (NumPy/BLAS, reference 6-GEMM formulation), %d of '
-                      '%d rows x %d iterations, time scaled x%d' % (rows, N_ROWS, iters, scale)}
+                      '%d rows x %d iterations (%.0f s), time scaled x%d'
+                      % (rows, N_ROWS, iters, per_iter * iters, scale)}
+
+
+def secondary_configs(torch, device):
+    """The other BASELINE configs at their one-GPU shapes, measured live in a few seconds each (they
+    are parity-test cases, not the headline; reported so that their numbers in DESIGN.md have a
+    driver-side record).  Synthetic data of SURVEY 8d's recipes."""
+    from decomp_amd import _arrays, _hip
+    out = {}
+    g = torch.Generator(device=device)
+    g.manual_seed(2)
+
+    def ms_of(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    # configs[2]: one dictionary-learning minibatch step, 8192 x 4096, k = 512, ista x 10, fp32
+    MB, F, K = 8192, 4096, 512
+    Dt = torch.randn((K, F), generator=g, device=device)
+    xt = 30.0 * torch.randn((MB, K), generator=g, device=device) * \
+        (torch.rand((MB, K), generator=g, device=device) < 0.05)
+    Y = xt @ Dt + 0.1 * torch.randn((MB, F), generator=g, device=device)
+    D = Dt + 0.2 * torch.randn((K, F), generator=g, device=device)
+    _arrays.l2_normalize_(D, strict=True)
+    x = torch.ones((MB, K), device=device)
+    A = torch.zeros((K, K), device=device)
+    B = torch.zeros((K, F), device=device)
+    D_new = torch.empty_like(D)
+    lib, h = _arrays.lib_handle(D)
+    md, lit = ctypes.c_double(0), ctypes.c_int(0)
+    state = {'D': D, 'Dn': D_new, 'count': 0}
+
+    def dl_step():
+        theta = state['count'] * MB + 1.0
+        _hip.check(h, lib.dcp_dict_step_f32(h, _arrays.ptr(Y), _arrays.ptr(x), _arrays.ptr(state['D']),
+                                            _arrays.ptr(state['Dn']), _arrays.ptr(A), _arrays.ptr(B), MB, F, K,
+                                            (theta - MB) / theta, 0.1, _hip.LASSO_ISTA, 10, 1e-5,
+                                            ctypes.byref(md), ctypes.byref(lit)), 'dict_step')
+        state['D'], state['Dn'] = state['Dn'], state['D']
+        state['count'] += 1
+    out['dictionary_step_ms'] = {'workload': 'configs[2] minibatch 8192x4096 k=512 ista x10 fp32',
+                                 'value': round(ms_of(dl_step, 6), 4)}
+    del Y, x, A, B, D, D_new, Dt, xt
+
+    # configs[3]: masked NMF MU, one GPU's shard 16384 x 4096, k = 256, 20 % missing, fp32
+    N, F, K = 16384, 4096, 256
+    Dt = torch.randn((K, F), generator=g, device=device).clamp_(min=0)
+    xt = torch.randn((N, K), generator=g, device=device).clamp_(min=0)
+    Y = xt @ Dt + 0.1 * torch.randn((N, F), generator=g, device=device).abs_()
+    D = (Dt + 0.3 * torch.randn((K, F), generator=g, device=device)).clamp_(min=0.1)
+    mask = (torch.rand((N, F), generator=g, device=device) >= 0.2).float()
+    _arrays.l2_normalize_(D, strict=True)
+    x = torch.ones((N, K), device=device)
+    it = ctypes.c_int(0)
+
+    def masked(n=5):
+        _hip.check(h, lib.dcp_nmf_mu_f32(h, _arrays.ptr(Y), _arrays.ptr(mask), _arrays.ptr(x), _arrays.ptr(D),
+                                         N, F, K, _hip.LIK_L2, ctypes.c_float(0.0), n + 1, ctypes.byref(it),
+                                         None, None), 'nmf_mu masked')
+    ms = ms_of(masked, 2) / 5
+    out['masked_nmf_ms_per_iter'] = {'workload': 'configs[3] shard 16384x4096 k=256 20% mask fp32',
+                                     'value': round(ms, 4),
+                                     'tflops_on_12NKF': round(12.0 * N * K * F / ms / 1e9, 1)}
+    # float64 (the reference's default dtype) on the fp64 MFMA core, same shard shape, no mask
+    Yd, Dd = Y.double(), D.double()
+    xd = torch.ones((N, K), device=device, dtype=torch.float64)
+
+    def f64(n=5):
+        _hip.check(h, lib.dcp_nmf_mu_f64(h, _arrays.ptr(Yd), None, _arrays.ptr(xd), _arrays.ptr(Dd), N, F, K,
+                                         _hip.LIK_L2, ctypes.c_double(0.0), n + 1, ctypes.byref(it), None,
+                                         None), 'nmf_mu f64')
+    ms = ms_of(f64, 2) / 5
+    W = 4.0 * N * K * F + 4.0 * N * K * K + 4.0 * K * K * F
+    out['f64_nmf_ms_per_iter'] = {'workload': '16384x4096 k=256 float64', 'value': round(ms, 4),
+                                  'tflops': round(W / ms / 1e9, 1), 'fp64_peak': 78.6}
+    return out
 
 
 def main():
@@ -105,6 +197,8 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the few-second side measurements of the other BASELINE configs')
     ap.add_argument('--no-kernel-events', action='store_true',
                     help='(analysis only) do not bracket kernel groups with hipEvents in the timed steps')
     ap.add_argument('--force-sharded', action='store_true',
@@ -256,6 +350,13 @@ def main():
                                           'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
                                           'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
                                           'launch_ms': st['ms_avg']}
+        if world == 1 and not args.rows and not args.no_secondary:
+            try:
+                del Y
+                torch.cuda.empty_cache()
+                out['secondary'] = secondary_configs(torch, device)
+            except Exception as e:      # never lose the headline line to a side measurement
+                out['secondary'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
