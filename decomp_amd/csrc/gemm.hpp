@@ -93,16 +93,18 @@ inline bool cplx_on_mfma(bool conjA, bool conjB, const void* ext_ws) {
 // 128x128, whose 68 tiles x 15 splits fill one round of 1024 resident workgroups.
 typedef TileCfg<256, 256, 16, 64, 64, 1> CfgHuge;      // 16 waves, 64 KiB LDS
 typedef TileCfg<128, 128, 16, 64, 64, 2> CfgLarge;     // 4 waves, 32 KiB LDS -> 4 WG/CU
+typedef TileCfg<128, 128, 16, 64, 32, 2> CfgMid;       // 8 waves: mid-size outputs (128..511 tiles), e.g.
+                                                      // y.A^H / v.AAt of an 8192-row minibatch: +8 % over 64x64
 typedef TileCfg<64, 64, 16, 32, 32, 2> CfgSmall;
 typedef TileCfg<32, 128, 32, 32, 32, 2> CfgFlat;       // <= 32 output rows (atom-block residuals)
 
-enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2, TIER_FLAT = 3 };
+enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2, TIER_FLAT = 3, TIER_MID = 4 };
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 inline void tier_dims(int tier, int& bm, int& bn) {
     if (tier == TIER_HUGE) { bm = CfgHuge::BM; bn = CfgHuge::BN; }
-    else if (tier == TIER_LARGE) { bm = CfgLarge::BM; bn = CfgLarge::BN; }
+    else if (tier == TIER_LARGE || tier == TIER_MID) { bm = CfgLarge::BM; bn = CfgLarge::BN; }
     else if (tier == TIER_FLAT) { bm = CfgFlat::BM; bn = CfgFlat::BN; }
     else { bm = 64; bn = 64; }
 }
@@ -125,6 +127,8 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
     // un-split products want at least two 4-wave workgroups per CU to hide latency
     const long wl = (long)ceil_div(M, CfgLarge::BM) * ceil_div(N, CfgLarge::BN);
     if (wl * splits >= (will_split ? 256 : 512)) return TIER_LARGE;
+    // one 128x128 tile per CU or fewer: 8 waves per tile instead of 4 keep two waves on every SIMD
+    if (FORM != FORM_TN && M >= 128 && N >= 128 && wl * splits >= 128) return TIER_MID;
     return TIER_SMALL;
 }
 
@@ -192,6 +196,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL, Epi>(stream, p, epi);
         if constexpr (FORM != FORM_TN) {
             if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL, Epi>(stream, p, epi);
+            if (tier == TIER_MID) return launch_gemm_mfma<CfgMid, AL, BL, Epi>(stream, p, epi);
         }
         return launch_gemm_mfma<CfgLarge, AL, BL, Epi>(stream, p, epi);
     } else {
@@ -233,6 +238,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
                     if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
                     if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL>(stream, p, ce);
+                    if (tier == TIER_MID) return launch_gemm_mfma<CfgMid, AL, BL>(stream, p, ce);
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
                 }
             }
