@@ -102,6 +102,66 @@ def test_reference_property_minimum():
         assert base < loss(x + rng.randn(*x.shape) * 1e-3, D + rng.randn(*D.shape) * 1e-3)
 
 
+class _RefDictProblem(object):
+    """setUp of tests/test_dictionary.py:35-43 (fresh per test method, as unittest does)."""
+    alpha = 0.1
+
+    def __init__(self, cplx):
+        self.rng = np.random.RandomState(0)
+        self.cplx = cplx
+        self.Dtrue = self.randn(3, 5)
+        self.xtrue = self.randn(101, 3) * self.rng.uniform(size=303).reshape(101, 3)
+        self.y = self.xtrue @ self.Dtrue + self.randn(101, 5) * 0.1
+        self.D = self.Dtrue + self.randn(3, 5) * 0.2
+        self.mask = np.rint(self.rng.uniform(0.45, 1, size=505)).reshape(101, 5)
+
+    def randn(self, *s):
+        return (self.rng.randn(*s) + self.rng.randn(*s) * 1.0j) if self.cplx else self.rng.randn(*s)
+
+    def error(self, x, D, m=None):
+        from oracle.common import l2
+        m = np.ones(self.y.shape) if m is None else m
+        a = self.alpha * np.sum(m, axis=-1, keepdims=True)
+        return np.sum(0.5 / a * np.square(np.abs(self.y - x @ l2(D))) * m) + np.sum(np.abs(x))
+
+    def assert_minimum(self, x, D, tol, n, m=None):
+        base = self.error(x, D, m)
+        for _ in range(n):
+            dx = self.randn(*x.shape) * tol
+            dD = self.randn(*D.shape) * tol
+            assert base < self.error(x + dx, D + dD, m)
+
+
+@pytest.mark.parametrize('cplx', [False, True])
+def test_reference_property_run(cplx):
+    """tests/test_dictionary.py:45-56 (TestFloat / TestComplex.test_run)."""
+    from decomp_amd import dictionary_learning as dl
+    p = _RefDictProblem(cplx)
+    it, D, x = dl.solve(p.y, p.D.copy(), p.alpha, x=None, tol=1.0e-4, method='block_cd', minibatch=100,
+                        maxiter=1000, lasso_method='acc_ista', lasso_iter=1000, random_seed=0)
+    assert it < 1000 - 1
+    p.assert_minimum(x, D, tol=1.0e-3, n=3)
+    assert not np.allclose(x, 0.0)
+
+
+@pytest.mark.parametrize('cplx', [False, True])
+def test_reference_property_run_mask(cplx):
+    """tests/test_dictionary.py:59-81 (test_run_mask; the reference checks the minimum against the
+    INITIAL dictionary, :74-75, and that a different minibatch size ends elsewhere)."""
+    from decomp_amd import dictionary_learning as dl
+    p = _RefDictProblem(cplx)
+    it, D, x = dl.solve(p.mask * p.y, p.D.copy(), p.alpha, x=None, tol=1.0e-4, minibatch=100,
+                        maxiter=1000, lasso_method='acc_ista', lasso_iter=1000, random_seed=0,
+                        mask=p.mask)
+    assert it < 1000 - 1
+    assert not np.allclose(x, 0.0)
+    Dinit = p.D.copy()
+    p.assert_minimum(x, Dinit, tol=1.0e-3, n=3, m=p.mask)
+    it2, D2, x2 = dl.solve(p.y, Dinit, p.alpha, x=None, tol=1.0e-5, minibatch=10, maxiter=1000,
+                           lasso_method='acc_ista', lasso_iter=1000, random_seed=0)
+    assert not np.allclose(Dinit, D2, atol=1.0e-4)
+
+
 def test_minibatch_container_roundtrip():
     """tests/test_utils.py: shuffle is cumulative, .array restores the original order, tail
     rows are skipped by the iteration."""
