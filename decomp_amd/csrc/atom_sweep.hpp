@@ -94,20 +94,47 @@ struct EpiAtomP {
     }
 };
 
+// Sum of one double per lane over the 64 lanes of a wave, with DPP row shifts / row broadcasts
+// (VALU latency) instead of the LDS crossbar of __shfl_xor (six dependent ds_bpermute pairs are
+// the longest chain of a recursion step otherwise).  Invalid / masked-out source lanes contribute
+// +0.0 (bound_ctrl, old = 0).  The total lands in lane 63 and is read back as a wave-uniform value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return x + __hiloint2double(shi, slo);
+}
+__device__ __forceinline__ double wave_sum_f64(double x) {
+    x = dpp_add_f64<0x111, 0xf>(x);   // row_shr:1
+    x = dpp_add_f64<0x112, 0xf>(x);   // row_shr:2
+    x = dpp_add_f64<0x114, 0xf>(x);   // row_shr:4
+    x = dpp_add_f64<0x118, 0xf>(x);   // row_shr:8   -> lane 15 of every row holds its row sum
+    x = dpp_add_f64<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
+    x = dpp_add_f64<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+
 // Step (3): ONE workgroup of 4 waves; lane i owns coefficient i, wave w takes every 4th term of
 // the two k-long sums of a step (the step is instruction-issue bound in a single wave: ~600 wide
 // instructions).  G (b x b, leading dim nb), Wl (leading dim kAtomBlkMax) -> E (leading dim nb).
 // Everything the b dependent steps touch is staged in LDS first (coalesced).
+// Two barriers per step: every wave forms c_k and E_k redundantly from the exchanged partial
+// sums, so rows E_j only ever have to be visible to the wave that consumes them (j mod 4 == w,
+// which is also the wave that stores them), and c_k is broadcast inside each wave through its own
+// LDS row -- same-wave LDS traffic is ordered, no workgroup barrier needed for either.
 template <class T>
 __global__ void __launch_bounds__(256) atom_recur_kernel(int nb, const T* __restrict__ G,
                                                          const T* __restrict__ Wl, T* __restrict__ E) {
     typedef typename wide_of<T>::type WT;
     typedef real_t<WT> WR;
     constexpr int BMAX = atom_blk<T>();
-    __shared__ WT sE[BMAX][BMAX + 1];   // rows E_j (wide type)
+    __shared__ WT sE[BMAX][BMAX + 1];   // rows E_j (wide type); row j is written and read by wave j % 4
     __shared__ T sG[BMAX][BMAX + 1];    // sG[i][i'] = G[i][i']
     __shared__ T sW[BMAX][BMAX + 1];    // sW[k][j] = w_kj
-    __shared__ WT sc[BMAX];
+    __shared__ WT sc[4][BMAX];          // c_k, one private copy per wave
     __shared__ WT spart[4][BMAX];       // per-wave partial sums
     __shared__ WR snorm[4];
     const int tid = threadIdx.x, i = tid & 63, w = tid >> 6;
@@ -133,39 +160,35 @@ __global__ void __launch_bounds__(256) atom_recur_kernel(int nb, const T* __rest
             for (; j < k; j += 4) acc = madd(acc, widen(sW[k][j]), sE[j][il]);
         }
         if (live) spart[w][i] = acc;
-        __syncthreads();
+        __syncthreads();                                        // barrier 1: partial sums
         WT c = sub((i == k) ? from_real<WT>(WR(1)) : zero_of<WT>(),
                    add(add(spart[0][il], spart[1][il]), add(spart[2][il], spart[3][il])));
         if (i >= nb || i > k) c = zero_of<WT>();   // support of c_k is i <= k
-        if (w == 0 && live) sc[i] = c;
-        __syncthreads();
+        if (live) sc[w][i] = c;                    // this wave's own copy (same-wave LDS order)
+        __builtin_amdgcn_wave_barrier();
         // |u_k|^2 = sum_{i,i'} c_i conj(c_i') G_ii'      (wave w: i' = w, w+4, ...)
         WT v = zero_of<WT>();
         if (i <= k && i < nb) {
             int ip = w;
             for (; ip + 12 <= k; ip += 16) {
-                const WT a0 = sc[ip], a1 = sc[ip + 4], a2 = sc[ip + 8], a3 = sc[ip + 12];
+                const WT a0 = sc[w][ip], a1 = sc[w][ip + 4], a2 = sc[w][ip + 8], a3 = sc[w][ip + 12];
                 const T g0 = sG[il][ip], g1 = sG[il][ip + 4], g2 = sG[il][ip + 8], g3 = sG[il][ip + 12];
                 v = madd(v, conj_of(a0), widen(g0));
                 v = madd(v, conj_of(a1), widen(g1));
                 v = madd(v, conj_of(a2), widen(g2));
                 v = madd(v, conj_of(a3), widen(g3));
             }
-            for (; ip <= k; ip += 4) v = madd(v, conj_of(sc[ip]), widen(sG[il][ip]));
+            for (; ip <= k; ip += 4) v = madd(v, conj_of(sc[w][ip]), widen(sG[il][ip]));
         }
-        WR part = real_part(mul(c, v));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        const WR part = wave_sum_f64(real_part(mul(c, v)));
         if (i == 0) snorm[w] = part;
-        __syncthreads();
+        __syncthreads();                                        // barrier 2: the four norm parts
         const WR tot = (snorm[0] + snorm[1]) + (snorm[2] + snorm[3]);
-        const WR s = sqrt(tot > WR(1) ? tot : WR(1));
-        const WT e = scale(c, WR(1) / s);
-        if (w == 0) {
-            if (live) sE[k][i] = e;
-            if (i < nb) E[(long)k * nb + i] = narrow<T>(e);
-        }
-        __syncthreads();   // sE[k] is read by the next step's first loop; snorm / spart are reused
+        const WT e = scale(c, rsqrt(tot > WR(1) ? tot : WR(1)));   // c / sqrt(max(|u_k|^2, 1))
+        if (w == (k & 3) && live) sE[k][i] = e;    // read back only by this same wave (j % 4 == w)
+        if (w == 0 && i < nb) E[(long)k * nb + i] = narrow<T>(e);
+        // next step: spart is rewritten only after every wave has passed barrier 2 (all reads of
+        // it sit between the barriers); snorm is rewritten only after barrier 1 of the next step
     }
 }
 
