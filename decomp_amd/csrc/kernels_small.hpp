@@ -263,9 +263,17 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const T* __restrict
     const long r0 = blockIdx.y * rows_per_blk;
     const long r1 = min(rows, r0 + rows_per_blk);
     for (long c = blockIdx.x * 256L + threadIdx.x; c < cols; c += (long)gridDim.x * 256L) {
-        T acc = zero_of<T>();
-        for (long r = r0; r < r1; ++r) acc = add(acc, a[r * ld + c]);
-        partial[blockIdx.y * cols + c] = acc;
+        // four independent running sums: the loop is load-latency bound with one
+        T a0 = zero_of<T>(), a1 = zero_of<T>(), a2 = zero_of<T>(), a3 = zero_of<T>();
+        long r = r0;
+        for (; r + 3 < r1; r += 4) {
+            a0 = add(a0, a[r * ld + c]);
+            a1 = add(a1, a[(r + 1) * ld + c]);
+            a2 = add(a2, a[(r + 2) * ld + c]);
+            a3 = add(a3, a[(r + 3) * ld + c]);
+        }
+        for (; r < r1; ++r) a0 = add(a0, a[r * ld + c]);
+        partial[blockIdx.y * cols + c] = add(add(a0, a1), add(a2, a3));
     }
 }
 
