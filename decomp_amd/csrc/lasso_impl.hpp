@@ -713,7 +713,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             a.ext_ws = w.ext2;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiSubFrom<T>{w.yAt, K, w.G, K})));
         }
-        if (K > 64 * 16) return fail(h, DCP_ERR_UNSUPPORTED, "cd: n_features > 1024 not supported");
+        if (K > 64 * 32) return fail(h, DCP_ERR_UNSUPPORTED, "cd: n_features > 2048 not supported");
         int sweep = 0;
         while (sweep < maxiter) {
             // run up to and including the next check sweep (sweeps 0, 10, 20, ...)
@@ -731,7 +731,8 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             else if (K <= 128) DCP_CD_LAUNCH(2);
             else if (K <= 256) DCP_CD_LAUNCH(4);
             else if (K <= 512) DCP_CD_LAUNCH(8);
-            else DCP_CD_LAUNCH(16);
+            else if (K <= 1024) DCP_CD_LAUNCH(16);
+            else DCP_CD_LAUNCH(32);
 #undef DCP_CD_LAUNCH
             DCP_LAUNCH_OK(h, hipGetLastError());
             sweep = last + 1;

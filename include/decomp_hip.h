@@ -199,7 +199,7 @@ int dcp_nmf_residual_f64(dcp_handle* h, const double* Y, const double* mask, con
  * *it_out (host) is the reference's iteration count: the index of the first iteration
  * i % 10 == 0 at which max(|dx| - tol) < 0, else maxiter - 1 (with the reference's
  * choice of returned iterate per method, lasso.py:297,357,415).  The coordinate-descent
- * solver supports K <= 1024.  Synchronises the stream before returning. */
+ * solver supports K <= 2048.  Synchronises the stream before returning. */
 int dcp_lasso_f32(dcp_handle* h, const float* Y, const float* mask, int mask_ndim, const float* A,
                   float* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
                   int method, int positive, int* it_out);

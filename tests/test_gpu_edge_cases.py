@@ -103,3 +103,21 @@ def test_dictionary_minibatch_equals_n_and_tail_rows():
         it, D, x = dl.solve(y.copy(), D0.copy(), 0.05, **kw)
         ito, Do, xo = odl.solve(y.copy(), D0.copy(), 0.05, **kw)
         assert it == ito and _close(D, Do, 1e-8) and _close(x, xo, 1e-8), mb
+
+
+@pytest.mark.parametrize('K', [1100, 2048])
+def test_lasso_cd_many_atoms(K):
+    """Coordinate descent with more than 1024 atoms (register-resident rows up to K = 2048):
+    three sweeps against the oracle's as-written sweep."""
+    from decomp_amd import lasso
+    from oracle import lasso as olasso
+    rng = np.random.RandomState(7)
+    N, F = 6, 96
+    A = rng.randn(K, F)
+    xt = rng.randn(N, K) * (rng.uniform(size=(N, K)) < 0.01)
+    y = xt @ A + 0.1 * rng.randn(N, F)
+    it, x = lasso.solve(y, A, 0.05, tol=1e-12, method='cd', maxiter=3)
+    ito, xo = olasso.solve(y.copy(), A.copy(), 0.05, tol=1e-12, method='cd', maxiter=3)
+    assert it == ito == 2
+    assert np.max(np.abs(x - xo)) <= 1e-9 * max(1.0, np.max(np.abs(xo)))
+    assert np.count_nonzero(x) > 0
