@@ -38,7 +38,7 @@ inline int dict_check(dcp_handle* h, const void* a, const void* b, const void* c
 // lasso_method arrives as DCP_LASSO_* optionally OR'ed with DCP_LASSO_POSITIVE ('_pos' solvers)
 inline bool dict_lasso_method_ok(int lasso_method) {
     const int base = lasso_method & ~DCP_LASSO_POSITIVE;
-    return base >= DCP_LASSO_ISTA && base <= DCP_LASSO_ADMM && base != DCP_LASSO_PARALLEL_CD;
+    return base >= DCP_LASSO_ISTA && base <= DCP_LASSO_ADMM;
 }
 
 template <class T>
@@ -48,16 +48,24 @@ inline int dict_lasso(dcp_handle* h, const T* Y, const real_t<T>* M, int mask_nd
     typedef real_t<T> R;
     const int base = lasso_method & ~DCP_LASSO_POSITIVE;
     const bool positive = (lasso_method & DCP_LASSO_POSITIVE) != 0;
+    LassoExtra extra;
+    if (base == DCP_LASSO_PARALLEL_CD) {   // the RNG stream of lasso.py:463,481 (dcp_dict_set_pcd_order)
+        if (!h->pcd_order || h->pcd_K != K || h->pcd_rows < lasso_iter)
+            return fail(h, DCP_ERR_INVALID, "parallel_cd inside the dictionary step: call "
+                                            "dcp_dict_set_pcd_order with >= lasso_iter rows of K entries");
+        extra.order = h->pcd_order;
+        extra.order_rows = h->pcd_rows;
+    }
     if constexpr (scalar_traits<T>::is_complex) {
         if (positive) return fail(h, DCP_ERR_INVALID, "positive solvers need a real dtype (lasso.py:92)");
         return lasso_solve<T, PROX_COMPLEX>(h, Y, M, mask_ndim, D, X, Nb, F, K, (R)alpha, (R)lasso_tol,
-                                            lasso_iter, base, it, lw);
+                                            lasso_iter, base, it, lw, extra);
     } else {
         if (positive)
             return lasso_solve<T, PROX_POSITIVE>(h, Y, M, mask_ndim, D, X, Nb, F, K, (R)alpha,
-                                                 (R)lasso_tol, lasso_iter, base, it, lw);
+                                                 (R)lasso_tol, lasso_iter, base, it, lw, extra);
         return lasso_solve<T, PROX_REAL>(h, Y, M, mask_ndim, D, X, Nb, F, K, (R)alpha, (R)lasso_tol,
-                                         lasso_iter, base, it, lw);
+                                         lasso_iter, base, it, lw, extra);
     }
 }
 

@@ -23,6 +23,9 @@ struct dcp_handle {
     void* host_pinned = nullptr;
     size_t host_pinned_bytes = 0;
     std::string err;
+    // parallel_cd inside the dictionary step: the caller-supplied shuffle table (dcp_dict_set_pcd_order)
+    const int* pcd_order = nullptr;
+    int64_t pcd_rows = 0, pcd_K = 0;
     // optional per-kernel timing (dcp_profile_*): hipEvent pairs around labelled launches
     bool prof_on = false;
     unsigned prof_mask = 0xffffffffu;   // labels that are timed while prof_on

@@ -509,4 +509,13 @@ int dcp_scatter_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, 
     return move_rows(h, in, nullptr, out, index, rows, row_bytes);
 }
 
+int dcp_dict_set_pcd_order(dcp_handle* h, const int32_t* order, int64_t rows, int64_t K) {
+    if (!h) return DCP_ERR_INVALID;
+    if (order != nullptr && (rows <= 0 || K <= 0)) return dcp::fail(h, DCP_ERR_INVALID, "bad table shape");
+    h->pcd_order = order;
+    h->pcd_rows = order ? rows : 0;
+    h->pcd_K = order ? K : 0;
+    return DCP_OK;
+}
+
 }  // extern "C"

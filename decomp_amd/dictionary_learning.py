@@ -100,6 +100,7 @@ def solve_cd(y, D, alpha, x, tol, minibatch, maxiter,
     lib, h = _arrays.lib_handle(D)
     step = getattr(lib, 'dcp_dict_step_' + sfx)
     code = lasso._dict_method_code(lasso_method)
+    pcd_table = lasso._dict_pcd_table(lasso_method, K, lasso_iter, D)    # noqa: F841 (kept alive)
     index = np.arange(y.size)                                            # :120
     A = torch.zeros((K, K), dtype=D.dtype, device=D.device)              # :122-123
     B = torch.zeros((K, F), dtype=D.dtype, device=D.device)
@@ -141,6 +142,7 @@ def solve_cd_mask(y, D, alpha, x, tol, minibatch, maxiter,
     lib, h = _arrays.lib_handle(D)
     step = getattr(lib, 'dcp_dict_mask_step_' + sfx)
     code = lasso._dict_method_code(lasso_method)
+    pcd_table = lasso._dict_pcd_table(lasso_method, K, lasso_iter, D)    # noqa: F841 (kept alive)
     index = np.arange(y.size)
     A = torch.zeros((K, F, K), dtype=D.dtype, device=D.device)           # :179
     B = torch.zeros((K, F), dtype=D.dtype, device=D.device)

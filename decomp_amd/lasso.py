@@ -31,17 +31,28 @@ _METHOD_CODE = {'ista': _hip.LASSO_ISTA, 'acc_ista': _hip.LASSO_ACC_ISTA,
 
 
 def _dict_method_code(lasso_method):
-    """Code of a solver name for the dcp_dict_* entry points ('_pos' -> DCP_LASSO_POSITIVE).
-    'parallel_cd' is not available inside the fused dictionary step (its RNG stream lives
-    on the host)."""
+    """Code of a solver name for the dcp_dict_* entry points ('_pos' -> DCP_LASSO_POSITIVE)."""
     base = lasso_method[:-4] if lasso_method.endswith('_pos') else lasso_method
-    if base not in _METHOD_CODE or base == 'parallel_cd':
-        raise NotImplementedError('lasso_method %s is not implemented inside the GPU '
-                                  'dictionary step' % lasso_method)
+    if base not in _METHOD_CODE:                                      # lasso.py:157-159
+        raise NotImplementedError('Method ' + base + ' is not yet implemented.')
     code = _METHOD_CODE[base]
     if lasso_method.endswith('_pos'):
         code |= _hip.LASSO_POSITIVE
     return code
+
+
+def _dict_pcd_table(lasso_method, K, lasso_iter, like):
+    """parallel_cd as the inner solver of the dictionary step: upload the shuffle table once and
+    hand it to the library (dcp_dict_set_pcd_order).  Returns the device table (keep it alive for
+    as long as the step entry points are called) or None for the other solvers."""
+    import torch
+    if not lasso_method.startswith('parallel_cd'):
+        return None
+    table = torch.from_numpy(_pcd_shuffle_table(K, max(int(lasso_iter), 1))).to(like.device)
+    lib, h = _arrays.lib_handle(like)
+    _hip.check(h, lib.dcp_dict_set_pcd_order(h, _arrays.ptr(table), table.shape[0], K),
+               'dcp_dict_set_pcd_order')
+    return table
 
 
 def _pcd_shuffle_table(K, rows):

@@ -148,6 +148,7 @@ class HipDictBackend(object):
         self.sfx = _arrays.suffix(D)
         self.K, self.F = D.shape
         self.code = lasso._dict_method_code(lasso_method)
+        self._pcd_table = lasso._dict_pcd_table(lasso_method, self.K, lasso_iter, D)
         self.lasso_iter, self.lasso_tol, self.alpha = int(lasso_iter), float(lasso_tol), float(alpha)
         self.stats = torch.empty((self.K, self.F + self.K), dtype=D.dtype, device=D.device)
         rdt = torch.float32 if D.dtype in (torch.float32, torch.complex64) else torch.float64

@@ -264,6 +264,12 @@ int dcp_gather_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, i
 int dcp_scatter_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
                            int64_t row_bytes, void* out);
 
+/* parallel_cd as the inner solver of the dictionary step (dcp_dict_*): the shuffle table of
+ * dcp_lasso_pcd_* (DEVICE int32 [rows, K], rows >= lasso_iter), remembered by the handle until
+ * replaced or cleared with order = NULL.  The reference restarts RandomState(0) in every call of the
+ * solver (lasso.py:463), so one table serves every minibatch.  The memory stays owned by the caller. */
+int dcp_dict_set_pcd_order(dcp_handle* h, const int32_t* order, int64_t rows, int64_t K);
+
 /* ---- online dictionary learning (block coordinate descent) -------------------------- */
 /* One minibatch step of decomp/dictionary_learning.py:135-164 (solve_cd), split at the
  * data-parallel exchange point like the NMF step:

@@ -53,7 +53,7 @@ def test_golden(name):
 
 
 @pytest.mark.parametrize('dt', ['float32', 'complex64'])
-@pytest.mark.parametrize('lm', ['ista', 'cd', 'admm', 'ista_pos', 'cd_pos'])
+@pytest.mark.parametrize('lm', ['ista', 'cd', 'admm', 'ista_pos', 'cd_pos', 'parallel_cd'])
 def test_against_oracle_medium(dt, lm):
     """1024 x 256, K = 64, minibatch 256, 2 epochs: float32 / complex64 (MFMA path for
     float32) against the CPU oracle."""
