@@ -400,6 +400,17 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     }
 }
 
+// hipFuncSetAttribute is per device: remember per (kernel instantiation, device) whether the
+// dynamic-LDS cap has been raised (one process normally drives one GPU, but nothing here assumes it).
+struct DynLdsRaised {
+    bool done[32] = {false};
+    bool& on_current_device() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return done[(dev >= 0 && dev < 32) ? dev : 0];
+    }
+};
+
 // Host-side launch helper.  Picks EDGE when any fast-path precondition fails.
 template <class Cfg, int ALAY, int BLAY, class Epi>
 inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi& epi) {
@@ -424,8 +435,8 @@ inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi&
                                    PanelGeom<BLAY, BN, BK, Cfg::NTHREADS>::ELEMS);
     constexpr int dyn_bytes = lds_bytes > 65536 ? lds_bytes : 0;
     if (dyn_bytes) {
-        static bool raised_fast = false, raised_edge = false;   // per instantiation
-        bool& raised = fast ? raised_fast : raised_edge;
+        static DynLdsRaised raised_fast, raised_edge;   // per instantiation
+        bool& raised = fast ? raised_fast.on_current_device() : raised_edge.on_current_device();
         if (!raised) {
             const void* fn = fast ? reinterpret_cast<const void*>(&gemm_mfma_kernel<Cfg, ALAY, BLAY, false, Epi>)
                                   : reinterpret_cast<const void*>(&gemm_mfma_kernel<Cfg, ALAY, BLAY, true, Epi>);

@@ -331,7 +331,8 @@ static int move_rows(dcp_handle* h, const void* in, const int64_t* in_index, voi
         // So the mover takes a dozen CUs for itself -- 1024 threads and the CU's whole LDS per
         // workgroup keep every other workgroup off them -- which is plenty to saturate the link
         // (12 x 64 KiB in flight) and costs the overlapped compute < 5 % of the chip.
-        static bool raised = false;
+        static DynLdsRaised raised_flag;
+        bool& raised = raised_flag.on_current_device();
         const int lds_bytes = 160 * 1024;
         if (!raised) {
             DCP_HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&move_rows_kernel<4>),
