@@ -114,3 +114,78 @@ def test_c4_shard_masked_properties():
     r1 = _resid(Y, a[2], a[1], mask)
     c = decomp_amd.nmf.solve(Y, a[1], x=a[2], tol=0.0, maxiter=4, mask=mask)
     assert _resid(Y, c[2], c[1], mask) <= r1
+
+
+def _dl_data(rows, F_, K_, cplx, seed=2):
+    """SURVEY 8d C3 / C5 recipe (amplitude 30 at 5 % density so that alpha * F leaves a sparse,
+    non-empty code)."""
+    import torch
+    g = torch.Generator(device='cuda')
+    g.manual_seed(seed)
+
+    def randn(*s):
+        r = torch.randn(s, generator=g, device='cuda')
+        return torch.complex(r, torch.randn(s, generator=g, device='cuda')) if cplx else r
+    Dt = randn(K_, F_)
+    xt = 30.0 * randn(rows, K_) * (torch.rand((rows, K_), generator=g, device='cuda') < 0.05)
+    Y = xt @ Dt + 0.1 * randn(rows, F_)
+    D0 = Dt + 0.2 * randn(K_, F_)
+    return Y, D0
+
+
+def _dl_objective(Y, x, D, alpha):
+    """Mean over rows of 1/(2 n) |y - x D|^2 + alpha |x|_1 with row-normalised D (the quantity
+    dictionary learning decreases, tests/test_dictionary.py:10-16)."""
+    import torch
+    Dn = D / torch.sqrt(torch.clamp(torch.sum(torch.abs(D) ** 2, dim=1, keepdim=True), min=1.0))
+    r = Y - x @ Dn
+    return float((0.5 / Y.shape[1] * torch.sum(torch.abs(r) ** 2) + alpha * torch.sum(torch.abs(x))) / Y.shape[0])
+
+
+@pytest.mark.parametrize('lasso_method', ['ista', 'cd'])
+def test_c3_dictionary_learning_properties(lasso_method):
+    """BASELINE configs[2] at its full minibatch shape (8192 x 4096, k = 512, alpha = 0.1, fp32), two
+    epochs over 4 minibatches: finite unit-norm-bounded atoms, sparse non-empty codes, identical result
+    on a re-run (deterministic split-K and shuffle), and a lower objective than the starting point."""
+    import torch
+    import decomp_amd
+    rows, F_, K_ = 4 * 8192, 4096, 512
+    Y, D0 = _dl_data(rows, F_, K_, cplx=False)
+    kw = dict(tol=0.0, minibatch=8192, maxiter=3, lasso_method=lasso_method, lasso_iter=10,
+              lasso_tol=1e-5, random_seed=0)
+    it, D, x = decomp_amd.dictionary_learning.solve(Y, D0, 0.1, **kw)
+    it2, D2, x2 = decomp_amd.dictionary_learning.solve(Y, D0, 0.1, **kw)
+    assert it == it2 == 3
+    assert torch.equal(D, D2) and torch.equal(x, x2)
+    assert bool(torch.isfinite(D).all()) and bool(torch.isfinite(x).all())
+    norms = torch.sqrt(torch.sum(D * D, dim=1))
+    assert float(norms.max()) <= 1.0 + 1e-4            # normalize.l2: |D_k| <= 1
+    dens = float((x != 0).float().mean())
+    assert 0.005 < dens < 0.3, dens
+    x_start = torch.ones_like(x)
+    assert _dl_objective(Y, x, D, 0.1) < _dl_objective(Y, x_start, D0, 0.1)
+
+
+def test_c5_complex_dictionary_step_properties():
+    """BASELINE configs[4] at one GPU's minibatch shape (8192 x 8192 complex64, k = 512): one epoch over
+    two minibatches; finite, sparse, deterministic, and the complex64 result agrees with the same run
+    in complex128 (fp64 MFMA core) to single precision."""
+    import torch
+    import decomp_amd
+    rows, F_, K_ = 2 * 8192, 8192, 512
+    Y, D0 = _dl_data(rows, F_, K_, cplx=True, seed=3)
+    kw = dict(tol=0.0, minibatch=8192, maxiter=2, lasso_method='ista', lasso_iter=10, lasso_tol=1e-5,
+              random_seed=0)
+    it, D, x = decomp_amd.dictionary_learning.solve(Y, D0, 0.1, **kw)
+    it2, D2, x2 = decomp_amd.dictionary_learning.solve(Y, D0, 0.1, **kw)
+    assert it == it2 == 2 and torch.equal(D, D2) and torch.equal(x, x2)
+    assert bool(torch.isfinite(torch.view_as_real(D)).all()) and bool(torch.isfinite(torch.view_as_real(x)).all())
+    dens = float((x != 0).float().mean())
+    assert 0.005 < dens < 0.3, dens
+    itd, Dd, xd = decomp_amd.dictionary_learning.solve(Y.to(torch.complex128), D0.to(torch.complex128), 0.1, **kw)
+    scale = float(torch.abs(Dd).max())
+    assert float(torch.abs(D.to(torch.complex128) - Dd).max()) < 2e-3 * scale
+    # codes: same support up to threshold-crossers, same values elsewhere
+    both = (x != 0) & (xd != 0)
+    assert float(both.float().sum()) > 0.98 * float((xd != 0).float().sum())
+    assert float(torch.abs(x.to(torch.complex128) - xd)[both].max()) < 2e-2 * float(torch.abs(xd).max())
