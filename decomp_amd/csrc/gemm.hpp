@@ -1,6 +1,7 @@
-// One GEMM front end for every dtype: float goes to the fp32 MFMA core
-// (gemm_mfma_f32.hpp), double / complex to the generic LDS-tiled core
-// (gemm_generic.hpp).  Epilogue functors (below) fuse the per-element update rules
+// One GEMM front end for every dtype: float and complex64 go to the fp32 MFMA core
+// (gemm_mfma_f32.hpp), double and complex128 to the fp64 MFMA core (gemm_mfma_f64.hpp) when the
+// output is at least 128 x 128; what is left (thin fp64 / complex128 outputs, complex products
+// without an extended-operand scratch) runs on the generic LDS-tiled VALU core (gemm_generic.hpp).  Epilogue functors (below) fuse the per-element update rules
 // of the solvers into the GEMM that produces their last operand.
 #pragma once
 #include <type_traits>

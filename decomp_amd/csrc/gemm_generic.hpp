@@ -1,12 +1,13 @@
-// Generic LDS-tiled GEMM for the dtypes that have no tuned MFMA path yet
-// (float64, complex64, complex128; also usable for float32 as a cross-check).
+// Generic LDS-tiled GEMM: the fallback of the front end (gemm.hpp) for products the MFMA cores do
+// not take -- float64 / complex128 outputs thinner than 128 x 128, complex products without an
+// extended-operand scratch -- and the cross-check of the MFMA cores in the tests (tile code 2).
 //
 //   C(m, n) = sum_k opA(A(m, k)) * opB(B(k, n)),  op = identity or conj
 //
 // Arbitrary element strides: A(m, k) at A[m*sAm + k*sAk], B(k, n) at
 // B[k*sBk + n*sBn].  64x64 tile, BK = 16, 256 threads, 4x4 outputs per thread,
 // fully bounds-checked (no alignment or divisibility requirement), split-K as in
-// the MFMA kernel.  VALU only: correct first, tuned later.
+// the MFMA kernel.  VALU only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "scalar.hpp"

@@ -458,7 +458,7 @@ const char* dcp_profile_label_name(int label) {
 const char* dcp_last_error_string(dcp_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
 const char* dcp_build_info(void) {
-    return "libdecomp_hip: gfx950, fp32 MFMA 32x32x2 GEMM core, HIP " DCP_STR(HIP_VERSION_MAJOR) "." DCP_STR(HIP_VERSION_MINOR);
+    return "libdecomp_hip: gfx950, fp32 MFMA 32x32x2 + fp64 MFMA 16x16x4 GEMM cores, HIP " DCP_STR(HIP_VERSION_MAJOR) "." DCP_STR(HIP_VERSION_MINOR);
 }
 
 int dcp_l2_normalize_f32(dcp_handle* h, float* U, int64_t K, int64_t F, int strict) {
