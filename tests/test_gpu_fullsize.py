@@ -189,3 +189,33 @@ def test_c5_complex_dictionary_step_properties():
     both = (x != 0) & (xd != 0)
     assert float(both.float().sum()) > 0.98 * float((xd != 0).float().sum())
     assert float(torch.abs(x.to(torch.complex128) - xd)[both].max()) < 2e-2 * float(torch.abs(xd).max())
+
+
+def test_c2_fp32_residual_trace_matches_fp64_to_1e5():
+    """north_star: "per-iteration residual matching NumPy to 1e-5 rel" at the FULL configs[1] shape,
+    where the NumPy oracle cannot run in seconds: the float32 path (fp32 MFMA, Gram formulation) against
+    the same data iterated in float64 (fp64 MFMA core, itself checked against the oracle at small sizes),
+    ||Y - x D||_F after each of the first 6 iterations."""
+    import ctypes
+    import torch
+    from decomp_amd import _arrays, _hip
+    Y, D0 = _data(N, seed=11)
+    n_it = 6
+
+    def trace(Yt, Dt, sfx, ctype):
+        D = Dt.clone()
+        _arrays.l2_normalize_(D, strict=True)
+        x = torch.ones((N, K), device='cuda', dtype=Yt.dtype)
+        lib, h = _arrays.lib_handle(Yt)
+        tr = (ctype * (n_it + 1))()
+        it = ctypes.c_int(0)
+        fn = getattr(lib, 'dcp_nmf_mu_' + sfx)
+        _hip.check(h, fn(h, _arrays.ptr(Yt), None, _arrays.ptr(x), _arrays.ptr(D), N, F, K, _hip.LIK_L2,
+                         ctype(0.0), n_it + 1, ctypes.byref(it), None, tr), 'nmf_mu_' + sfx)
+        assert it.value == n_it + 1
+        return np.array([tr[i] for i in range(n_it)], dtype=np.float64)
+    r32 = trace(Y, D0, 'f32', ctypes.c_float)
+    r64 = trace(Y.double(), D0.double(), 'f64', ctypes.c_double)
+    rel = np.abs(r32 - r64) / r64
+    assert np.all(np.diff(r64) <= 0)            # MU never increases the loss
+    assert rel.max() <= 1e-5, rel
