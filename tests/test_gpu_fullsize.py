@@ -219,3 +219,35 @@ def test_c2_fp32_residual_trace_matches_fp64_to_1e5():
     rel = np.abs(r32 - r64) / r64
     assert np.all(np.diff(r64) <= 0)            # MU never increases the loss
     assert rel.max() <= 1e-5, rel
+
+
+@pytest.mark.parametrize('lik', ['l2', 'kl'])
+def test_c4_shard_masked_fp32_trace_matches_fp64(lik):
+    """The same check for one 16384-row shard of the masked configs[3] (20 % missing), l2 and kl:
+    masked residual ||(Y - x D) o M||_F per iteration, float32 vs float64."""
+    import ctypes
+    import torch
+    from decomp_amd import _arrays, _hip
+    rows = 16384
+    Y, D0 = _data(rows, seed=13)
+    g = torch.Generator(device='cuda')
+    g.manual_seed(17)
+    mask = (torch.rand((rows, F), generator=g, device='cuda') >= 0.2).float()
+    n_it = 5
+    code = _hip.LIK_L2 if lik == 'l2' else _hip.LIK_KL
+
+    def trace(Yt, Mt, Dt, sfx, ctype):
+        D = Dt.clone()
+        _arrays.l2_normalize_(D, strict=True)
+        x = torch.ones((rows, K), device='cuda', dtype=Yt.dtype)
+        lib, h = _arrays.lib_handle(Yt)
+        tr = (ctype * (n_it + 1))()
+        it = ctypes.c_int(0)
+        fn = getattr(lib, 'dcp_nmf_mu_' + sfx)
+        _hip.check(h, fn(h, _arrays.ptr(Yt), _arrays.ptr(Mt), _arrays.ptr(x), _arrays.ptr(D), rows, F, K,
+                         code, ctype(0.0), n_it + 1, ctypes.byref(it), None, tr), 'nmf_mu_' + sfx)
+        return np.array([tr[i] for i in range(n_it)], dtype=np.float64)
+    r32 = trace(Y, mask, D0, 'f32', ctypes.c_float)
+    r64 = trace(Y.double(), mask.double(), D0.double(), 'f64', ctypes.c_double)
+    rel = np.abs(r32 - r64) / r64
+    assert rel.max() <= 1e-5, rel
