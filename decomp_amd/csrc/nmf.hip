@@ -92,54 +92,13 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     int result_it = maxiter;   // batch_mu.py:26
     T md_last = T(0);
     bool converged = false;
-
-    // One iteration = ~10 launches.  When the kernels are short (small problems: the reference's
-    // own test sizes up to a few thousand rows) the loop is launch bound, so the two iteration
-    // shapes (odd / even: the x and D buffers alternate) are captured ONCE into hipGraphs after
-    // two eager warm-up iterations and replayed with one hipGraphLaunch each.  At the BASELINE
-    // sizes the host is never the bottleneck and the eager path stays.
-    auto enqueue_iteration = [&](int slot, T* xc, T* xn, T* dc, T* dn) -> int {
-        DCP_TRY(nmf_stats<T>(h, Ypre, mask, xc, xn, dc, s, stats, ws));
-        DCP_TRY(nmf_update<T>(h, stats, dc, dn, F, K, lik, masked, maxdiff_dev + slot, wu,
+    for (int it = 1; it < maxiter; ++it) {  // batch_mu.py:16
+        const int slot = it & 1;
+        DCP_TRY(nmf_stats<T>(h, Ypre, mask, Xc, Xn, Dc, s, stats, ws));
+        DCP_TRY(nmf_update<T>(h, stats, Dc, Dn, F, K, lik, masked, maxdiff_dev + slot, wu,
                               maxdiff_dev + (slot ^ 1)));
         DCP_HIP_OK(h, hipMemcpyAsync(host_md + slot, maxdiff_dev + slot, sizeof(T),
                                      hipMemcpyDeviceToHost, h->stream));
-        return DCP_OK;
-    };
-    const double iter_flops = 12.0 * (double)N * (double)K * (double)F;
-    bool use_graph = !h->prof_on && !want_resid && maxiter > 8 && iter_flops < 2.0e10;
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};
-    struct GraphGuard {
-        hipGraphExec_t* g;
-        ~GraphGuard() { for (int i = 0; i < 2; ++i) if (g[i]) (void)hipGraphExecDestroy(g[i]); }
-    } graph_guard{gexec};
-
-    for (int it = 1; it < maxiter; ++it) {  // batch_mu.py:16
-        const int slot = it & 1;
-        bool launched = false;
-        if (use_graph && it >= 3) {
-            if (!gexec[slot]) {   // capture this parity's iteration (nothing executes while capturing)
-                hipGraph_t graph = nullptr;
-                bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-                int rc = DCP_OK;
-                if (ok) {
-                    rc = enqueue_iteration(slot, Xc, Xn, Dc, Dn);
-                    ok = (hipStreamEndCapture(h->stream, &graph) == hipSuccess) && rc == DCP_OK && graph;
-                }
-                if (ok) ok = hipGraphInstantiate(&gexec[slot], graph, nullptr, nullptr, 0) == hipSuccess;
-                if (graph) (void)hipGraphDestroy(graph);
-                if (!ok) {        // capture is an optimisation: fall back to eager launches
-                    (void)hipGetLastError();
-                    gexec[slot] = nullptr;
-                    use_graph = false;
-                }
-            }
-            if (use_graph && gexec[slot]) {
-                DCP_HIP_OK(h, hipGraphLaunch(gexec[slot], h->stream));
-                launched = true;
-            }
-        }
-        if (!launched) DCP_TRY(enqueue_iteration(slot, Xc, Xn, Dc, Dn));
         DCP_HIP_OK(h, hipEventRecord(ev[slot], h->stream));
         if (want_resid) {   // parity/debug mode: synchronous
             DCP_TRY(nmf_residual<T>(h, Y, mask, Xn, Dn, N, F, K, resid_tmp, resid_part,
