@@ -129,7 +129,9 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
     const long wl = (long)ceil_div(M, CfgLarge::BM) * ceil_div(N, CfgLarge::BN);
     if (wl * splits >= (will_split ? 256 : 512)) return TIER_LARGE;
     // one 128x128 tile per CU or fewer: 8 waves per tile instead of 4 keep two waves on every SIMD
-    if (FORM != FORM_TN && M >= 128 && N >= 128 && wl * splits >= 128) return TIER_MID;
+    // (deep reductions only: measured on y.A^H, K = 4096, +8 %; for K = 256..512 products -- x.G, the
+    //  ISTA step -- the 64x64 tile with its 4x more workgroups is as fast or faster)
+    if (FORM != FORM_TN && M >= 128 && N >= 128 && K >= 1024 && wl * splits >= 128) return TIER_MID;
     return TIER_SMALL;
 }
 
