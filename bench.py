@@ -13,8 +13,9 @@ synthetic (SURVEY 8d recipe) and resident in HBM before the timed region.
 
 Rank 0 prints one JSON line.  `roofline` is the dominant kernel (the fused
 Y.D^T + quotient GEMM) timed with HIP events on the solver's own stream inside the timed
-steps; `cpu_baseline` is the NumPy oracle (the reference's formulation) on a bounded
-sample of the same workload on this host's cores (N = 1, rank 0 only).
+steps; `cpu_baseline` is the NumPy oracle (the reference's formulation) timed at the FULL shape
+on this host's cores and `parity` the per-iteration residual of the HIP path against that same
+oracle run, on the timed run's own Y (N = 1, rank 0 only).
 """
 import argparse
 import ctypes
@@ -69,44 +70,114 @@ def pmc_traffic(kernel_key):
     return None, 'kernel not in PMC summary'
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle (NumPy restatement of the reference's 6-GEMM formulation) on a bounded
-    row sample of the same workload, scaled to whole-job iterations/s."""
-    import numpy as np
-    from oracle import nmf as onmf, common
+def host_cpu_info():
+    """(model name, physical cores inside this process's affinity mask, logical cpus in the mask)."""
     try:
-        affinity = len(os.sched_getaffinity(0))
+        affinity = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        affinity = os.cpu_count() or 1
-    cores, blas = affinity, 'unknown'
-    try:    # the threads the BLAS behind NumPy really runs (what `cores` must state)
-        from threadpoolctl import threadpool_info
-        pools = [p for p in threadpool_info() if p.get('user_api') == 'blas']
-        if pools:
-            cores = int(max(p.get('num_threads', 1) for p in pools))
-            blas = '%s %s' % (pools[0].get('internal_api'), pools[0].get('version'))
+        affinity = list(range(os.cpu_count() or 1))
+    model, cores = 'unknown', set()
+    try:
+        cur = {}
+        for line in open('/proc/cpuinfo'):
+            if ':' in line:
+                k, v = [t.strip() for t in line.split(':', 1)]
+                cur[k] = v
+                if k == 'model name':
+                    model = v
+            elif cur:
+                if int(cur.get('processor', -1)) in affinity:
+                    cores.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor'))))
+                cur = {}
+        if cur and int(cur.get('processor', -1)) in affinity:
+            cores.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor'))))
     except Exception:
         pass
-    rows = 4096
-    rng = np.random.RandomState(0)
-    Dt = np.maximum(rng.randn(N_ATOMS, N_FEAT), 0).astype(np.float32)
-    xt = np.maximum(rng.randn(rows, N_ATOMS), 0).astype(np.float32)
-    y = xt @ Dt + 0.1 * np.abs(rng.randn(rows, N_FEAT)).astype(np.float32)
-    D = common.l2_strict(np.maximum(Dt + 0.3 * rng.randn(N_ATOMS, N_FEAT), 0.1).astype(np.float32))
-    x = np.ones((rows, N_ATOMS), np.float32)
-    x, D, _ = onmf.mu_step(y, x, D)           # warm-up (BLAS threads, page faults)
-    t0 = time.perf_counter()
-    iters = 0
-    while iters < 3 or (time.perf_counter() - t0 < budget_s and iters < 400):
-        x, D, _ = onmf.mu_step(y, x, D)
-        iters += 1
-    per_iter = (time.perf_counter() - t0) / iters
-    scale = N_ROWS / rows
-    return {'value': 1.0 / (per_iter * scale), 'unit': 'iterations/s', 'cores': cores,
-            'kind': 'port', 'blas': blas, 'affinity_cores': affinity,
-            'sample': 'oracle.nmf.mu_step (NumPy/BLAS, reference 6-GEMM formulation), %d of '
-                      '%d rows x %d iterations (%.0f s), time scaled x%d'
-                      % (rows, N_ROWS, iters, per_iter * iters, scale)}
+    return model, (len(cores) or len(affinity)), len(affinity)
+
+
+def host_residual(y, x, d, block=8192):
+    """||y - x d||_F with float64 accumulation, evaluated on the host in row blocks (the same
+    function scores the GPU's and the oracle's iterates, so a difference can only come from x, D)."""
+    import numpy as np
+    acc = 0.0
+    for r0 in range(0, y.shape[0], block):
+        r = y[r0:r0 + block] - x[r0:r0 + block].dot(d)
+        acc += float(np.sum(np.square(r, dtype=np.float64)))
+    return acc ** 0.5
+
+
+def parity_and_cpu_baseline(torch, lib, h, Y, D0, timed_iters=3):
+    """SURVEY 8(d) "parity gates run with every benchmark" + the CPU baseline, both at the FULL
+    configs[1] shape on the very Y the GPU was timed on:
+      * the NumPy oracle (oracle.nmf.mu_step: the reference's 6-GEMM formulation, grads.py:108-125,
+        batch_mu.py:16-24) and the HIP path each run 1 + timed_iters MU iterations from the same
+        (Y, D0, x = ones); after every iteration ||Y - x D||_F of both is evaluated on the host by
+        the same function and must agree to 1e-5 relative (north_star);
+      * cpu_baseline = the oracle's measured seconds per iteration over the last `timed_iters`
+        iterations (the first one warms up BLAS threads and page faults), BLAS threads = physical
+        cores of this process's affinity mask."""
+    import numpy as np
+    from decomp_amd import _arrays, _hip
+    from oracle import nmf as onmf, common
+    model, phys, logical = host_cpu_info()
+    threads, blas, limiter = phys, 'unknown', None
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        pools = [p for p in threadpool_info() if p.get('user_api') == 'blas']
+        if pools:
+            blas = '%s %s' % (pools[0].get('internal_api'), pools[0].get('version'))
+        limiter = threadpool_limits(limits=phys, user_api='blas')
+        pools = [p for p in threadpool_info() if p.get('user_api') == 'blas']
+        if pools:   # what the BLAS really runs with (a build-time thread cap may sit below `phys`)
+            threads = int(max(p.get('num_threads', 1) for p in pools))
+    except Exception:
+        pass
+    n_rows = Y.shape[0]
+    y = Y.cpu().numpy()
+    d0 = D0.cpu().numpy()
+    n_it = 1 + timed_iters
+    # ---- HIP path, one iteration per call (dcp_nmf_mu with maxiter = 2) ----
+    xg = torch.ones((n_rows, N_ATOMS), dtype=torch.float32, device=Y.device)
+    Dg = D0.clone()
+    _arrays.l2_normalize_(Dg, strict=True)                      # nmf.py:70
+    it = ctypes.c_int(0)
+    gpu_iter = []
+    for _ in range(n_it):
+        _hip.check(h, lib.dcp_nmf_mu_f32(h, _arrays.ptr(Y), None, _arrays.ptr(xg), _arrays.ptr(Dg), n_rows,
+                                         N_FEAT, N_ATOMS, _hip.LIK_L2, ctypes.c_float(0.0), 2,
+                                         ctypes.byref(it), None, None), 'dcp_nmf_mu_f32 (parity)')
+        gpu_iter.append((xg.cpu().numpy(), Dg.cpu().numpy()))
+    del xg, Dg
+    # ---- oracle ----
+    x = np.ones((n_rows, N_ATOMS), np.float32)
+    d = common.l2_strict(d0)
+    res_cpu, res_gpu, times = [], [], []
+    for i in range(n_it):
+        t0 = time.perf_counter()
+        x, d, _ = onmf.mu_step(y, x, d)
+        times.append(time.perf_counter() - t0)
+        res_cpu.append(host_residual(y, x, d))
+        res_gpu.append(host_residual(y, *gpu_iter[i]))
+    if limiter is not None:
+        limiter.restore_original_limits()
+    rel = [abs(a - b) / b for a, b in zip(res_gpu, res_cpu)]
+    per_iter = sum(times[1:]) / max(1, len(times) - 1)
+    tol = 1.0e-5
+    parity = {'shape': '%dx%d k=%d fp32' % (n_rows, N_FEAT, N_ATOMS), 'iterations': n_it,
+              'metric': '||Y - x D||_F after each MU iteration, HIP path vs NumPy oracle '
+                        '(oracle.nmf.mu_step), both evaluated on the host',
+              'rel_err': [float('%.3e' % r) for r in rel], 'rel_err_max': max(rel),
+              'residual_oracle': res_cpu, 'residual_hip': res_gpu, 'tolerance': tol,
+              'pass': bool(max(rel) <= tol)}
+    base = {'value': 1.0 / per_iter, 'unit': 'iterations/s', 'cores': threads, 'kind': 'port',
+            'blas': blas, 'cpu_model': model, 'physical_cores': phys, 'affinity_cpus': logical,
+            's_per_iteration': per_iter,
+            'sample': 'oracle.nmf.mu_step (NumPy/BLAS, reference 6-GEMM formulation) at the FULL '
+                      '%dx%d k=%d fp32 shape on the GPU run\'s own Y: %d timed iterations after 1 '
+                      'warm-up (%.1f s), %d BLAS threads' % (n_rows, N_FEAT, N_ATOMS, len(times) - 1,
+                                                             sum(times), threads)}
+    return parity, base
 
 
 def secondary_configs(torch, device):
@@ -350,6 +421,9 @@ def main():
                                           'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
                                           'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
                                           'launch_ms': st['ms_avg']}
+        if world == 1 and not args.rows and not args.no_cpu_baseline:
+            # full-shape oracle parity gate + measured CPU baseline (same Y as the timed run)
+            out['parity'], out['cpu_baseline'] = parity_and_cpu_baseline(torch, lib, h, Y, D0)
         if world == 1 and not args.rows and not args.no_secondary:
             try:
                 del Y
@@ -357,9 +431,9 @@ def main():
                 out['secondary'] = secondary_configs(torch, device)
             except Exception as e:      # never lose the headline line to a side measurement
                 out['secondary'] = {'error': repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
+        if 'parity' in out and not out['parity']['pass']:
+            raise SystemExit('parity gate FAILED: %r' % (out['parity'],))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -11,6 +11,7 @@ All arithmetic runs in hand-written HIP kernels (libdecomp_hip.so, gfx950) behin
 plain C ABI (include/decomp_hip.h); there is no CPU fallback.
 """
 from . import nmf, lasso, nnls, dictionary_learning  # noqa: F401
+from . import utils, math_utils, nmf_methods  # noqa: F401
 from .utils import exceptions  # noqa: F401
 
 __version__ = '0.1.0'

@@ -90,6 +90,14 @@ SIGNATURES = {
     'dcp_nmf_apply_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_f64, _c_vp, _c_i64, _c_i64, _P(_c_f64)]),
     'dcp_axpby_f32': (_c_int, [_c_vp, _c_i64, _c_f64, _c_vp, _c_f64, _c_vp]),
     'dcp_axpby_f64': (_c_int, [_c_vp, _c_i64, _c_f64, _c_vp, _c_f64, _c_vp]),
+    'dcp_mu_quotient_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_mu_quotient_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_l2_normalize_diff_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_int, _P(_c_f64)]),
+    'dcp_l2_normalize_diff_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_int, _P(_c_f64)]),
+    'dcp_gershgorin_f32': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_gershgorin_f64': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_gershgorin_c64': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_gershgorin_c128': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_calib_read_f32': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_int, _c_vp]),
     'dcp_gemm_c64': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                               _c_int, _c_int]),

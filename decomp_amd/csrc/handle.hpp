@@ -13,6 +13,7 @@
 struct dcp_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t stream_switch = nullptr;   // orders the shared arena across dcp_set_stream changes
     // Workspace: one grow-only arena.  A public call plans its total need, reserves it
     // (ws_reserve: reallocates only when the plan outgrows the arena, i.e. on the first
     // call of a given problem size, never in steady state), then bumps (ws_alloc).

@@ -520,6 +520,11 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
     typedef real_t<T> R;
     hipStream_t st = h->stream;
     const int N = (int)N64, F = (int)F64, K = (int)K64;
+    // The Gram-form coordinate descent keeps a row's K coefficients in one wave's registers
+    // (64 lanes x 32 slots).  Checked before anything is enqueued; parallel_cd is included
+    // because it falls back to cd when p <= 1 (lasso.py:468-470).
+    if ((method == DCP_LASSO_CD || method == DCP_LASSO_PARALLEL_CD) && mask_ndim != 2 && K > 64 * 32)
+        return fail(h, DCP_ERR_UNSUPPORTED, "cd: n_features > 2048 not supported");
     void* hostv = nullptr;
     DCP_TRY(host_scratch(h, 64, &hostv));
     int* host_flag = reinterpret_cast<int*>(hostv);
@@ -713,7 +718,6 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             a.ext_ws = w.ext2;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiSubFrom<T>{w.yAt, K, w.G, K})));
         }
-        if (K > 64 * 32) return fail(h, DCP_ERR_UNSUPPORTED, "cd: n_features > 2048 not supported");
         int sweep = 0;
         while (sweep < maxiter) {
             // run up to and including the next check sweep (sweeps 0, 10, 20, ...)

@@ -278,10 +278,17 @@ __global__ void __launch_bounds__(256) nmf_rule_kernel(const T* __restrict__ D, 
 }
 
 template <class T>
-__global__ void __launch_bounds__(256) axpby_kernel(long n, T a, const T* __restrict__ x, T b,
-                                                    T* __restrict__ y) {
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
-        y[i] = a * x[i] + b * y[i];
+__global__ void __launch_bounds__(256) axpby_kernel(long n, T a, const T* x, T b, T* y) {
+    // a zero coefficient means "do not read that operand" (BLAS semantics): y may be
+    // uninitialised when b == 0, and 0 * NaN / 0 * Inf must not leak into the result.
+    // x and y may alias (no __restrict__).
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        T v;
+        if (b == T(0)) v = a * x[i];
+        else if (a == T(0)) v = b * y[i];
+        else v = a * x[i] + b * y[i];
+        y[i] = v;
+    }
 }
 
 template <class T>

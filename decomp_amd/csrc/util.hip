@@ -389,13 +389,24 @@ int dcp_destroy(dcp_handle* h) {
         (void)hipEventDestroy(r.b);
     }
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
+    if (h->stream_switch) (void)hipEventDestroy(h->stream_switch);
     delete h;
     return DCP_OK;
 }
 
 int dcp_set_stream(dcp_handle* h, void* hip_stream) {
     if (!h) return DCP_ERR_INVALID;
-    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
+    if (next != h->stream && h->arena != nullptr) {
+        // The workspace arena is shared by every call on this handle: work already enqueued on the
+        // old stream may still be using it, so the new stream waits for it (an event, no host sync).
+        DCP_HIP_OK(h, hipSetDevice(h->device));
+        if (h->stream_switch == nullptr)
+            DCP_HIP_OK(h, hipEventCreateWithFlags(&h->stream_switch, hipEventDisableTiming));
+        DCP_HIP_OK(h, hipEventRecord(h->stream_switch, h->stream));
+        DCP_HIP_OK(h, hipStreamWaitEvent(next, h->stream_switch, 0));
+    }
+    h->stream = next;
     return DCP_OK;
 }
 

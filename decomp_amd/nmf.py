@@ -25,12 +25,19 @@ _JITTER = 1.0e-15
 
 
 def _likelihood_code(likelihood):
-    """grads.py:7-14.  User-supplied Likelihood objects (grads.py:12-13) are a Python
-    plugin point of the reference that cannot run inside the HIP kernels."""
-    if likelihood in ('l2', 'gaussian'):
-        return _hip.LIK_L2
-    if likelihood in ('kl', 'poisson'):
-        return _hip.LIK_KL
+    """grads.py:7-14: the kernel code (an int) of a built-in likelihood, or the user-supplied
+    ``Likelihood`` instance itself (grads.py:12-13), which then runs through the host loop
+    ``_run_mu_user`` / ``nmf_minibatch._UserKernels``."""
+    from .nmf_methods import grads
+    if isinstance(likelihood, str):
+        if likelihood in ('l2', 'gaussian'):
+            return _hip.LIK_L2
+        if likelihood in ('kl', 'poisson'):
+            return _hip.LIK_KL
+    elif type(likelihood) in (grads.Gaussian, grads.Poisson):
+        return likelihood._code
+    elif isinstance(likelihood, grads.Likelihood):
+        return likelihood
     raise NotImplementedError('Likelihood {} is not implemented for nmf'.format(likelihood))
 
 
@@ -93,7 +100,7 @@ def solve(y, D, x=None, tol=1.0e-3, minibatch=None, maxiter=1000, method='mu',
         x_dev = _arrays.to_device(x_given, dev, copy=True)   # updated in place
     assertion.assert_nonnegative(x_dev)
     lik = None
-    if likelihood in ['kl']:                                          # nmf.py:67-68
+    if isinstance(likelihood, str) and likelihood in ['kl']:          # nmf.py:67-68
         y_dev = _arrays.to_device(y, dev)
         assertion.assert_nonnegative(y_dev)
     else:
@@ -108,9 +115,12 @@ def solve(y, D, x=None, tol=1.0e-3, minibatch=None, maxiter=1000, method='mu',
                 raise TypeError('solve() got an unexpected keyword argument %r'
                                 % sorted(kwargs)[0])
             lik = _likelihood_code(likelihood)
+            get_array_module(y, mask)
+            if not isinstance(lik, int):
+                it, D_dev, x_dev = _run_mu_user(y, mask, x_dev, D_dev, lik, tol, maxiter, kind)
+                return it, _arrays.to_caller(D_dev, kind), _arrays.to_caller(x_dev, kind)
             if y_dev is None:
                 y_dev = _arrays.to_device(y, dev)
-            get_array_module(y, mask)
             m_dev = _arrays.to_device(mask, dev)
             it = _run_mu(y_dev, m_dev, x_dev, D_dev, lik, tol, maxiter)
             return it, _arrays.to_caller(D_dev, kind), _arrays.to_caller(x_dev, kind)
@@ -132,10 +142,10 @@ def solve(y, D, x=None, tol=1.0e-3, minibatch=None, maxiter=1000, method='mu',
     rng = np.random.RandomState(random_seed)
     if method in ['asg-mu', 'gsg-mu', 'asag-mu', 'gsag-mu']:
         it, Dout, xout = nmf_minibatch.solve_serizel(ybat, D_dev, xbat, tol, minibatch, maxiter,
-                                                     method, lik, mbat, rng, **kwargs)
+                                                     method, lik, mbat, rng, kind=kind, **kwargs)
     else:
         it, Dout, xout = nmf_minibatch.solve_kasai(ybat, D_dev, xbat, tol, minibatch, maxiter,
-                                                   method, lik, mbat, rng, **kwargs)
+                                                   method, lik, mbat, rng, kind=kind, **kwargs)
     return it, _arrays.to_caller(Dout, kind), _arrays.to_caller(xout, kind)
 
 
@@ -160,13 +170,13 @@ def _solve_streamed(y, D_dev, x_given, tol, minibatch, maxiter, method, likeliho
             if needs_update:
                 assertion.assert_nonnegative(t)                       # nmf.py:65
             return MinibatchData(t, minibatch)
-        if needs_update or likelihood in ['kl']:
+        if needs_update or (isinstance(likelihood, str) and likelihood in ['kl']):
             assertion.assert_nonnegative_host_or_device(a)            # nmf.py:65,67-68
         return AsyncMinibatchData(a, minibatch, needs_update=needs_update, device=dev)
 
     if x_given is None:                                               # nmf.py:53-54: ones in D's module
         x_given = torch.ones((y.shape[0], D_dev.shape[0]), dtype=D_dev.dtype, device=D_dev.device)
-    if _arrays.is_torch(y) and likelihood in ['kl']:
+    if _arrays.is_torch(y) and isinstance(likelihood, str) and likelihood in ['kl']:
         assertion.assert_nonnegative(_arrays.to_device(y, dev))
     _arrays.l2_normalize_(D_dev, strict=True)                         # nmf.py:70
     lik = _likelihood_code(likelihood)
@@ -204,3 +214,36 @@ def _run_mu(y, mask, x, D, lik, tol, maxiter, resid_trace=None):
         n_done = it.value if it.value < maxiter else maxiter - 1
         resid_trace.extend(float(trace[i]) for i in range(max(n_done, 0)))
     return it.value
+
+
+def _run_mu_user(y, mask, x_dev, D_dev, lik, tol, maxiter, kind):
+    """batch_mu.py:8-26 with a user-supplied Likelihood (grads.py:12-13).  The plugin's
+    ``update_x`` / ``update_d`` see arrays of the caller's kind (NumPy or torch CUDA); the
+    inherited update rule, ``l2_strict`` and the stop test run on the GPU
+    (``dcp_mu_quotient_*``, ``dcp_l2_normalize_diff_*``).  Returns (it, D, x) as device tensors."""
+    import torch
+    dev = D_dev.device.index
+    sfx = _arrays.suffix(D_dev)
+    K, F = D_dev.shape
+    md = ctypes.c_double(0.0)
+
+    def user(t):
+        return _arrays.to_caller(t, kind)
+
+    y_u = y if kind == 'numpy' else _arrays.to_device(y, dev)
+    m_u = mask if (mask is None or kind == 'numpy') else _arrays.to_device(mask, dev)
+    x, D = x_dev, D_dev
+    D_new = torch.empty_like(D)
+    for it in range(1, maxiter):                                       # batch_mu.py:16
+        x = _arrays.to_device(lik.update_x(y_u, user(x), user(D), m_u), dev)
+        U = _arrays.to_device(lik.update_d(y_u, user(x), user(D), m_u), dev)
+        if U.shape != D.shape or U.dtype != D.dtype:
+            raise ValueError('update_d must return an array like D: %s %s' % (tuple(U.shape), U.dtype))
+        lib, h = _arrays.lib_handle(D)
+        fn = getattr(lib, 'dcp_l2_normalize_diff_' + sfx)
+        _hip.check(h, fn(h, _arrays.ptr(U), _arrays.ptr(D), _arrays.ptr(D_new), K, F, 1,
+                         ctypes.byref(md)), 'dcp_l2_normalize_diff')
+        if md.value < tol:                                             # batch_mu.py:22
+            return it, D_new, x
+        D, D_new = D_new, D
+    return maxiter, D, x

@@ -43,12 +43,41 @@ class _Kernels(object):
         _hip.check(h, fn(h, y.numel(), float(a), _arrays.ptr(x), float(b), _arrays.ptr(y)), 'dcp_axpby')
 
 
-def solve_serizel(y, D, x, tol, minibatch, maxiter, method, lik, mask, rng, forget_rate=0.5):
+class _UserKernels(_Kernels):
+    """The same three operations with a user-supplied Likelihood (grads.py:12-13) standing in for
+    the fused gradient kernel: the plugin's ``grad_x`` / ``grad_d`` run on arrays of the caller's
+    kind, the update rule (``dcp_mu_quotient_*``) and everything else on the GPU."""
+
+    def __init__(self, D, lik, kind):
+        _Kernels.__init__(self, D, -1)
+        self.user, self.kind = lik, kind
+
+    def grads(self, y_mb, m_mb, x_mb, D, n_x_updates, gpos, gneg):
+        from .nmf_methods.grads import mu_quotient
+
+        def user(t):
+            return None if t is None else _arrays.to_caller(t, self.kind)
+        dev = D.device.index
+        yu, mu, Du = user(y_mb), user(m_mb), user(D)
+        for _ in range(int(n_x_updates)):                  # serizel.py:46-49
+            pos, neg = self.user.grad_x(yu, user(x_mb), Du, mu)
+            x_mb.copy_(_arrays.to_device(mu_quotient(user(x_mb), pos, neg), dev))
+        pos, neg = self.user.grad_d(yu, user(x_mb), Du, mu)
+        gpos.copy_(_arrays.to_device(pos, dev).expand(gpos.shape))
+        gneg.copy_(_arrays.to_device(neg, dev).expand(gneg.shape))
+
+
+def _kernels_for(D, lik, kind):
+    return _Kernels(D, lik) if isinstance(lik, int) else _UserKernels(D, lik, kind)
+
+
+def solve_serizel(y, D, x, tol, minibatch, maxiter, method, lik, mask, rng, forget_rate=0.5,
+                  kind='torch'):
     """serizel.py:9-165.  y, x, mask: decomp_amd.utils.data.MinibatchData / NoneIterator.
     QUIRK kept: 'gsg-mu' runs the asg algorithm (serizel.py:23-25); on convergence the OLD
     D is returned (serizel.py:58-59)."""
     import torch
-    kern = _Kernels(D, lik)
+    kern = _kernels_for(D, lik, kind)
     gpos, gneg = torch.empty_like(D), torch.empty_like(D)
     D_new = torch.empty_like(D)
     averaged = method in ('asag-mu', 'gsag-mu')
@@ -79,7 +108,8 @@ def solve_serizel(y, D, x, tol, minibatch, maxiter, method, lik, mask, rng, forg
     return maxiter, D, x.array
 
 
-def solve_kasai(y, D, x, tol, minibatch, maxiter, method, lik, mask, rng, alpha=1.0, beta=0.5):
+def solve_kasai(y, D, x, tol, minibatch, maxiter, method, lik, mask, rng, alpha=1.0, beta=0.5,
+                kind='torch'):
     """kasai.py:10-88 (SVRMU / SVRMU-ACC)."""
     import torch
     if method == 'svrmu':
@@ -88,7 +118,7 @@ def solve_kasai(y, D, x, tol, minibatch, maxiter, method, lik, mask, rng, alpha=
         F, K = D.shape
         N = x.shape[0]
         iter_minibatch = int(np.maximum(beta * F * (3 * K + 2 * N) / (3 * F * N + 2 * K), 1.0))
-    kern = _Kernels(D, lik)
+    kern = _kernels_for(D, lik, kind)
     index = np.arange(y.size)
     rng.shuffle(index)                                     # kasai.py:42-46: shuffled ONCE
     y.shuffle(index)

@@ -1,1 +1,1 @@
-from . import assertion, dtype, exceptions, data  # noqa: F401
+from . import assertion, dtype, exceptions, data, normalize, cp_compat  # noqa: F401

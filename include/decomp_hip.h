@@ -96,6 +96,14 @@ int dcp_l2_normalize_c128(dcp_handle* h, void* U, int64_t K, int64_t F, int stri
 int dcp_count_negative_f32(dcp_handle* h, const float* x, int64_t n, int64_t* count);
 int dcp_count_negative_f64(dcp_handle* h, const double* x, int64_t n, int64_t* count);
 
+/* math_utils/eigen.py:9-20 (spectral_radius_Gershgorin): for a batch X[batch, n, n],
+ * out[b] = max_j sum_i |X[b, i, j]| (DEVICE array of the real dtype, length batch).
+ * Asynchronous on the handle's stream. */
+int dcp_gershgorin_f32(dcp_handle* h, const float* X, int64_t batch, int64_t n, float* out);
+int dcp_gershgorin_f64(dcp_handle* h, const double* X, int64_t batch, int64_t n, double* out);
+int dcp_gershgorin_c64(dcp_handle* h, const void* X, int64_t batch, int64_t n, float* out);
+int dcp_gershgorin_c128(dcp_handle* h, const void* X, int64_t batch, int64_t n, double* out);
+
 /* Test hook (not a reference interface): C[M,N] = op(A) . op(B) through the same GEMM
  * cores the solvers use.  form: 0 = NT (A[M,K], B[N,K]), 1 = NN (A[M,K], B[K,N]),
  * 2 = TN (A[K,M], B[K,N]).  ksplits >= 1 selects split-K (partials summed in order).
@@ -169,7 +177,9 @@ int dcp_nmf_mu_update_f64(dcp_handle* h, const double* stats, const double* D, d
  *   dcp_nmf_apply_*: D_new = l2_strict(rule) and max|D - D_new| to the host:
  *                    alpha <  0: D o max(P,0)/max(Q,1e-15)                 (serizel.py:54-57)
  *                    alpha >= 0: max(D o ((1-alpha) + alpha P/max(Q,1e-15)), 0)  (kasai.py:77-78)
- *   dcp_axpby_*    : y = a x + b y  (gradient averaging serizel.py:95-96, kasai.py:74-75). */
+ *   dcp_axpby_*    : y = a x + b y  (gradient averaging serizel.py:95-96, kasai.py:74-75); a zero
+ *                    coefficient means its operand is not read (y may be uninitialised when b = 0);
+ *                    x may alias y. */
 int dcp_nmf_grads_f32(dcp_handle* h, const float* Y, const float* mask, float* X, const float* D,
                       int64_t N, int64_t F, int64_t K, int likelihood, int n_x_updates,
                       float* grad_pos, float* grad_neg);
@@ -182,6 +192,20 @@ int dcp_nmf_apply_f64(dcp_handle* h, const double* D, const double* P, const dou
                       double* D_new, int64_t K, int64_t F, double* maxdiff);
 int dcp_axpby_f32(dcp_handle* h, int64_t n, double a, const float* x, double b, float* y);
 int dcp_axpby_f64(dcp_handle* h, int64_t n, double a, const double* x, double b, double* y);
+
+/* Likelihood.update_x / update_d (decomp/nmf_methods/grads.py:77-93), the multiplicative rule a
+ * user-supplied Likelihood subclass inherits:  out = cur o max(pos, 0) / max(neg, 1e-15), all
+ * [rows, cols] contiguous (out may alias cur).  Asynchronous on the handle's stream. */
+int dcp_mu_quotient_f32(dcp_handle* h, const float* cur, const float* pos, const float* neg,
+                        int64_t rows, int64_t cols, float* out);
+int dcp_mu_quotient_f64(dcp_handle* h, const double* cur, const double* pos, const double* neg,
+                        int64_t rows, int64_t cols, double* out);
+/* The tail of one MU iteration for a caller-produced U (batch_mu.py:21-22 with a user Likelihood):
+ * out = l2_strict(U) (strict != 0) or l2(U), *maxdiff (HOST) = max |ref - out|.  Synchronises. */
+int dcp_l2_normalize_diff_f32(dcp_handle* h, const float* U, const float* ref, float* out, int64_t K,
+                              int64_t F, int strict, double* maxdiff);
+int dcp_l2_normalize_diff_f64(dcp_handle* h, const double* U, const double* ref, double* out, int64_t K,
+                              int64_t F, int strict, double* maxdiff);
 
 /* ||(Y - X D) o mask||_F (parity metric of SURVEY 8d; mask nullable). */
 int dcp_nmf_residual_f32(dcp_handle* h, const float* Y, const float* mask, const float* X,

@@ -1,7 +1,8 @@
-"""GPU: BASELINE.json's full sizes through size-independent properties (the oracle cannot
-run these shapes in seconds): Y 65536 x 4096, k = 256, float32 (configs[1]) and one
-16384-row shard of the masked configs[3].  Data are synthesised on the GPU with torch
-(test plumbing only)."""
+"""GPU: BASELINE.json's full sizes.  Primary evidence: the NumPy oracle itself iterated at the
+full configs[1] shape (Y 65536 x 4096, k = 256, float32) and at one 16384-row masked shard of
+configs[3] for three MU iterations, per-iteration residual within 1e-5 relative (north_star).
+Then size-independent properties and fp32-vs-fp64 traces.  Data are synthesised on the GPU with
+torch (test plumbing only)."""
 import numpy as np
 import pytest
 
@@ -29,6 +30,68 @@ def _resid(Y, x, D, mask=None):
     _hip.check(h, lib.dcp_nmf_residual_f32(h, _arrays.ptr(Y), _arrays.ptr(mask), _arrays.ptr(x),
                                            _arrays.ptr(D), Y.shape[0], F, K, ctypes.byref(out)), 'resid')
     return out.value
+
+
+def _host_residual(y, x, d, mask=None, block=8192):
+    """||(y - x d) o mask||_F, float64 accumulation, on the host in row blocks: the SAME function
+    scores the HIP path's and the oracle's iterates."""
+    acc = 0.0
+    for r0 in range(0, y.shape[0], block):
+        r = y[r0:r0 + block] - x[r0:r0 + block].dot(d)
+        if mask is not None:
+            r = r * mask[r0:r0 + block]
+        acc += float(np.sum(np.square(r, dtype=np.float64)))
+    return acc ** 0.5
+
+
+def _oracle_vs_hip(rows, seed, masked, n_it=3):
+    """n_it MU iterations of the NumPy oracle (oracle.nmf.mu_step = the reference's formulation,
+    grads.py:108-125 + batch_mu.py:16-24) and of the HIP path from the same (Y, D0, x = ones);
+    returns the per-iteration relative residual differences and max|D - D_oracle|."""
+    import ctypes
+    import torch
+    from decomp_amd import _arrays, _hip
+    from oracle import nmf as onmf, common
+    Y, D0 = _data(rows, seed=seed)
+    mask = None
+    if masked:
+        g = torch.Generator(device='cuda')
+        g.manual_seed(seed + 100)
+        mask = (torch.rand((rows, F), generator=g, device='cuda') >= 0.2).float()
+    y, d0 = Y.cpu().numpy(), D0.cpu().numpy()
+    m = None if mask is None else mask.cpu().numpy()
+    xg = torch.ones((rows, K), device='cuda')
+    Dg = D0.clone()
+    _arrays.l2_normalize_(Dg, strict=True)
+    lib, h = _arrays.lib_handle(Y)
+    it = ctypes.c_int(0)
+    x, d = np.ones((rows, K), np.float32), common.l2_strict(d0)
+    rel, ddiff = [], []
+    for _ in range(n_it):
+        _hip.check(h, lib.dcp_nmf_mu_f32(h, _arrays.ptr(Y), _arrays.ptr(mask), _arrays.ptr(xg), _arrays.ptr(Dg),
+                                         rows, F, K, _hip.LIK_L2, ctypes.c_float(0.0), 2, ctypes.byref(it),
+                                         None, None), 'dcp_nmf_mu_f32')
+        x, d, _ = onmf.mu_step(y, x, d, m)
+        r_cpu = _host_residual(y, x, d, m)
+        r_hip = _host_residual(y, xg.cpu().numpy(), Dg.cpu().numpy(), m)
+        rel.append(abs(r_hip - r_cpu) / r_cpu)
+        ddiff.append(float(np.max(np.abs(Dg.cpu().numpy() - d))))
+    return rel, ddiff
+
+
+def test_c2_oracle_parity_full_shape():
+    """north_star: "per-iteration residual matching NumPy to 1e-5 rel" at the FULL configs[1] shape,
+    against the NumPy oracle itself (SURVEY 8d "parity gates ... at C2 for 3 iterations")."""
+    rel, ddiff = _oracle_vs_hip(N, seed=21, masked=False)
+    assert max(rel) <= 1e-5, rel
+    assert max(ddiff) <= 1e-5, ddiff          # unit-norm rows: absolute = relative scale
+
+
+def test_c4_shard_oracle_parity_masked():
+    """The same gate for one 16384-row shard of the masked configs[3] (20 % missing)."""
+    rel, ddiff = _oracle_vs_hip(16384, seed=23, masked=True)
+    assert max(rel) <= 1e-5, rel
+    assert max(ddiff) <= 1e-5, ddiff
 
 
 def test_c2_properties():
@@ -144,12 +207,12 @@ def _dl_objective(Y, x, D, alpha):
 
 @pytest.mark.parametrize('lasso_method', ['ista', 'cd'])
 def test_c3_dictionary_learning_properties(lasso_method):
-    """BASELINE configs[2] at its full minibatch shape (8192 x 4096, k = 512, alpha = 0.1, fp32), two
-    epochs over 4 minibatches: finite unit-norm-bounded atoms, sparse non-empty codes, identical result
+    """BASELINE configs[2] at its full shape (Y 65536 x 4096, k = 512, alpha = 0.1, fp32, minibatch 8192),
+    two epochs over 8 minibatches: finite unit-norm-bounded atoms, sparse non-empty codes, identical result
     on a re-run (deterministic split-K and shuffle), and a lower objective than the starting point."""
     import torch
     import decomp_amd
-    rows, F_, K_ = 4 * 8192, 4096, 512
+    rows, F_, K_ = 65536, 4096, 512
     Y, D0 = _dl_data(rows, F_, K_, cplx=False)
     kw = dict(tol=0.0, minibatch=8192, maxiter=3, lasso_method=lasso_method, lasso_iter=10,
               lasso_tol=1e-5, random_seed=0)
@@ -193,7 +256,7 @@ def test_c5_complex_dictionary_step_properties():
 
 def test_c2_fp32_residual_trace_matches_fp64_to_1e5():
     """north_star: "per-iteration residual matching NumPy to 1e-5 rel" at the FULL configs[1] shape,
-    where the NumPy oracle cannot run in seconds: the float32 path (fp32 MFMA, Gram formulation) against
+    secondary evidence next to test_c2_oracle_parity_full_shape, over more iterations: the float32 path (fp32 MFMA, Gram formulation) against
     the same data iterated in float64 (fp64 MFMA core, itself checked against the oracle at small sizes),
     ||Y - x D||_F after each of the first 6 iterations."""
     import ctypes
