@@ -18,7 +18,10 @@ def _normalize(U, axis, strict):
     ax = axis % nd
     moved = t.movedim(ax, -1) if ax != nd - 1 else t
     shape = moved.shape
-    flat = moved.reshape(-1, shape[-1]).clone()          # clone: the kernel works in place
+    import torch
+    # a fresh C-contiguous copy (the kernel works in place; clone() alone would keep the strides
+    # of a transposed view)
+    flat = moved.reshape(-1, shape[-1]).clone(memory_format=torch.contiguous_format)
     if flat.numel():
         _arrays.l2_normalize_(flat, strict=strict)
     out = flat.reshape(shape)

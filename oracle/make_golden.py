@@ -375,6 +375,81 @@ def gen_dl(ref, out):
     print('dictionary learning: %d cases' % len(cases))
 
 
+def dl_inputs_wide(seed, N, F, K, complex_):
+    """The recipe of tests/test_dictionary.py:35-43 at a wider dictionary (K > 64 atoms: several
+    blocks of the blocked atom sweep, csrc/atom_sweep.hpp)."""
+    rng = np.random.RandomState(seed)
+
+    def randn(*s):
+        if complex_:
+            return rng.randn(*s) + rng.randn(*s) * 1.0j
+        return rng.randn(*s)
+
+    Dt = randn(K, F)
+    xt = randn(N, K) * (rng.uniform(size=N * K).reshape(N, K) < 0.05)
+    y = np.dot(xt, Dt) + randn(N, F) * 0.1
+    D0 = Dt + randn(K, F) * 0.2
+    return y, D0
+
+
+def gen_dl_extra(ref, out):
+    """(1) float32 / complex64 runs of the dl_golden cases (BASELINE configs[2] and [4] dtypes);
+    (2) wide dictionaries (K = 160 real: two full 64-atom blocks + a 32-atom tail; K = 80 complex),
+    all dtypes, so that the blocked atom sweep is pinned to the real reference."""
+    data = {}
+    cases = []
+    for complex_ in (False, True):
+        y64, D064, mask64 = dl_inputs(0, complex_)
+        cdt = np.complex64 if complex_ else np.float32
+        y, D0, mask = y64.astype(cdt), D064.astype(cdt), mask64.astype(np.float32)
+        base = 'dl_%s' % ('c64' if complex_ else 'f32')
+        data[base + '/y'] = y
+        data[base + '/D0'] = D0
+        data[base + '/mask'] = mask
+        for minibatch in (100, 10):
+            for lasso_method, lasso_iter in (('ista', 10), ('acc_ista', 30), ('cd', 10)):
+                for use_mask in (False, True):
+                    if use_mask and (minibatch != 10 or lasso_method == 'cd'):
+                        continue
+                    for epochs in (1, 2):
+                        yy = y * mask if use_mask else y
+                        it, D, x = ref.dictionary_learning.solve(
+                            yy.copy(), D0.copy(), 0.1, x=None, tol=0.0,
+                            minibatch=minibatch, maxiter=epochs + 1,
+                            lasso_method=lasso_method, lasso_iter=lasso_iter,
+                            lasso_tol=1.0e-5, random_seed=0,
+                            mask=mask.copy() if use_mask else None)
+                        name = '%s/mb%d/%s%d/%s/ep%d' % (
+                            base, minibatch, lasso_method, lasso_iter,
+                            'mask' if use_mask else 'nomask', epochs)
+                        cases.append(name)
+                        data[name + '/it'] = np.int64(it)
+                        data[name + '/D'] = D
+                        data[name + '/x'] = x
+    for tag, complex_, cdt, K in (('f64', False, np.float64, 160), ('f32', False, np.float32, 160),
+                                  ('c128', True, np.complex128, 80), ('c64', True, np.complex64, 80)):
+        N, F = 384, 48
+        y64, D064 = dl_inputs_wide(1, N, F, K, complex_)
+        y, D0 = y64.astype(cdt), D064.astype(cdt)
+        base = 'dlwide_%s' % tag
+        data[base + '/y'] = y
+        data[base + '/D0'] = D0
+        for lasso_method, lasso_iter in (('ista', 10), ('cd', 10)):
+            for epochs in (1, 2):
+                it, D, x = ref.dictionary_learning.solve(
+                    y.copy(), D0.copy(), 0.02, x=None, tol=0.0, minibatch=128,
+                    maxiter=epochs + 1, lasso_method=lasso_method,
+                    lasso_iter=lasso_iter, lasso_tol=1.0e-5, random_seed=0)
+                name = '%s/%s%d/ep%d' % (base, lasso_method, lasso_iter, epochs)
+                cases.append(name)
+                data[name + '/it'] = np.int64(it)
+                data[name + '/D'] = D
+                data[name + '/x'] = x
+    data['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(out, 'dl_extra_golden.npz'), **data)
+    print('dictionary learning (f32 / c64 / wide): %d cases' % len(cases))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -391,6 +466,7 @@ def main():
     gen_lasso(ref, args.out)
     gen_lasso_extra(ref, args.out)
     gen_dl(ref, args.out)
+    gen_dl_extra(ref, args.out)
     return 0
 
 

@@ -52,6 +52,85 @@ def test_golden(name):
     assert _err(x, g[name + '/x']) < 1e-7, (name, _err(x, g[name + '/x']))
 
 
+def _gx():
+    return np.load(os.path.join(GOLDEN, 'dl_extra_golden.npz'), allow_pickle=False)
+
+
+def _extra_cases():
+    return [str(c) for c in _gx()['cases']]
+
+
+@pytest.mark.parametrize('name', _extra_cases())
+def test_golden_single_precision_and_wide(name):
+    """Reference-generated fixtures (oracle/make_golden.py::gen_dl_extra): float32 / complex64 runs of
+    the reference's own test shapes (the dtypes of BASELINE configs[2] and [4]) and wide dictionaries,
+    K = 160 real (two full 64-atom blocks + a 32-atom tail of the blocked atom sweep) and K = 80
+    complex, in all four dtypes."""
+    from decomp_amd import dictionary_learning as dl
+    from test_oracle_golden import _run_dl_case
+    g = _gx()
+    it, D, x = _run_dl_case(dl.solve, g, name)
+    Dg, xg = g[name + '/D'], g[name + '/x']
+    assert it == int(g[name + '/it']), name
+    assert D.dtype == Dg.dtype and x.dtype == xg.dtype and x.shape == xg.shape
+    single = Dg.dtype in (np.float32, np.complex64)
+    # double precision: rounding-level agreement (the blocked sweep forms norms through a Gram
+    # matrix); single precision: 2e-4 of the largest entry, the bound the CPU oracle itself meets
+    tol_D = 2e-4 if single else 1e-7
+    tol_x = 5e-4 if single else 1e-7
+    assert _err(D, Dg) < tol_D, (name, _err(D, Dg))
+    assert _err(x, xg) < tol_x, (name, _err(x, xg))
+
+
+@pytest.mark.parametrize('dt,K', [('float64', 160), ('float32', 160), ('float64', 200),
+                                  ('complex128', 80), ('complex64', 80), ('float64', 64), ('float32', 33)])
+def test_atom_sweep_direct_against_oracle(dt, K):
+    """dcp_dict_update_* alone (A/B accumulation + the blocked Gauss-Seidel atom sweep + max|dD|)
+    against oracle.dictionary_learning.atom_sweep (dictionary_learning.py:154-159) for dictionaries
+    wider than one 64-atom block, incl. a tail block and a zero code column (the A_kk + 1e-15
+    blow-up that l2 then renormalises)."""
+    import ctypes
+    import torch
+    from decomp_amd import _arrays, _hip
+    from oracle import dictionary_learning as odl
+    from oracle.common import l2_strict
+    rng = np.random.RandomState(K)
+    cplx = dt.startswith('complex')
+    Nb, F = 300, 96
+
+    def randn(*s):
+        return (rng.randn(*s) + 1j * rng.randn(*s)) if cplx else rng.randn(*s)
+    x = (randn(Nb, K) * (rng.uniform(size=(Nb, K)) < 0.15)).astype(dt)
+    x[:, 5] = 0                                           # an unused atom
+    y = randn(Nb, F).astype(dt)
+    D = l2_strict(randn(K, F)).astype(dt)
+    A_old = (np.conj(x.T) @ x).astype(dt) * 0.5
+    B_old = (np.conj(x.T) @ y).astype(dt) * 0.5
+    beta = 0.75
+    stats = np.concatenate([np.conj(x.T) @ y, np.conj(x.T) @ x], axis=1).astype(dt)
+    A_ref = beta * A_old + stats[:, F:]
+    B_ref = beta * B_old + stats[:, :F]
+    D_ref = odl.atom_sweep(D, A_ref, B_ref)
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    st, A, B, Dd = t(stats), t(A_old), t(B_old), t(D)
+    D_new = torch.empty_like(Dd)
+    rdt = torch.float32 if dt in ('float32', 'complex64') else torch.float64
+    md = torch.zeros((1,), dtype=rdt, device='cuda')
+    lib, h = _arrays.lib_handle(Dd)
+    fn = getattr(lib, 'dcp_dict_update_' + _arrays.suffix(Dd))
+    _hip.check(h, fn(h, _arrays.ptr(st), beta, _arrays.ptr(A), _arrays.ptr(B), _arrays.ptr(Dd),
+                     _arrays.ptr(D_new), F, K, _arrays.ptr(md)), 'dcp_dict_update')
+    torch.cuda.synchronize()
+    single = dt in ('float32', 'complex64')
+    tol = 2e-4 if single else 1e-9
+    assert _err(A.cpu().numpy(), A_ref) < (1e-5 if single else 1e-12)
+    assert _err(B.cpu().numpy(), B_ref) < (1e-5 if single else 1e-12)
+    assert _err(D_new.cpu().numpy(), D_ref) < tol, _err(D_new.cpu().numpy(), D_ref)
+    want_md = float(np.max(np.abs(D - D_ref)))
+    assert abs(float(md.item()) - want_md) <= tol * max(1.0, want_md)
+
+
 @pytest.mark.parametrize('dt', ['float32', 'complex64'])
 @pytest.mark.parametrize('lm', ['ista', 'cd', 'admm', 'ista_pos', 'cd_pos', 'parallel_cd'])
 def test_against_oracle_medium(dt, lm):

@@ -41,9 +41,15 @@ def test_golden_cases(kind, sname, mname):
             xr = g[name + '/x']
             assert x.shape == xr.shape and x.dtype == y.dtype, name
             if kind == 'f32':
-                assert _err(x, xr) < 1e-3, (name, _err(x, xr))
+                # float32: the solution within 2e-4 of the largest entry; the iteration count exact
+                # on exhaustion and within ONE stop check (the test fires every 10th iteration,
+                # lasso.py:293) on converged cases, where the last |dx| < tol decision is made on
+                # single-precision rounding noise
+                assert _err(x, xr) < 2e-4, (name, _err(x, xr))
                 if tag == 'exh':
                     assert it == int(g[name + '/it']), name
+                else:
+                    assert abs(it - int(g[name + '/it'])) <= 10, (name, it, int(g[name + '/it']))
             else:
                 assert it == int(g[name + '/it']), (name, it, int(g[name + '/it']))
                 assert _err(x, xr) < 1e-8, (name, _err(x, xr))

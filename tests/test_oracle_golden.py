@@ -182,6 +182,44 @@ def test_dictionary_learning_all_cases(golden_dir):
         assert _close(x, g[name + '/x'], 1.0e-9), name
 
 
+def _run_dl_case(solve, g, name):
+    """Re-run one case of dl_extra_golden.npz (names as oracle/make_golden.py::gen_dl_extra)."""
+    parts = name.split('/')
+    base = parts[0]
+    y, D0 = g[base + '/y'], g[base + '/D0']
+    if base.startswith('dlwide_'):
+        lm = parts[1].rstrip('0123456789')
+        li = int(parts[1][len(lm):])
+        epochs = int(parts[2][2:])
+        return solve(y.copy(), D0.copy(), 0.02, tol=0.0, minibatch=128, maxiter=epochs + 1,
+                     lasso_method=lm, lasso_iter=li, lasso_tol=1.0e-5, random_seed=0)
+    mask = g[base + '/mask']
+    minibatch = int(parts[1][2:])
+    lm = parts[2].rstrip('0123456789')
+    li = int(parts[2][len(lm):])
+    use_mask = parts[3] == 'mask'
+    epochs = int(parts[4][2:])
+    yy = y * mask if use_mask else y
+    return solve(yy.copy(), D0.copy(), 0.1, tol=0.0, minibatch=minibatch, maxiter=epochs + 1,
+                 lasso_method=lm, lasso_iter=li, lasso_tol=1.0e-5, random_seed=0,
+                 mask=mask.copy() if use_mask else None)
+
+
+def test_dictionary_learning_extra_cases(golden_dir):
+    """float32 / complex64 runs of the reference's own test shapes and wide dictionaries
+    (K = 160 / 80 atoms: several blocks of the product's blocked atom sweep)."""
+    g = _load(golden_dir, 'dl_extra_golden.npz')
+    cases = [str(c) for c in g['cases']]
+    assert len(cases) == 48
+    for name in cases:
+        it, D, x = _run_dl_case(odl.solve, g, name)
+        single = g[name + '/D'].dtype in (np.float32, np.complex64)
+        assert D.dtype == g[name + '/D'].dtype and x.dtype == g[name + '/x'].dtype, name
+        assert it == int(g[name + '/it']), name
+        assert _close(D, g[name + '/D'], 2.0e-4 if single else 1.0e-9), name
+        assert _close(x, g[name + '/x'], 2.0e-4 if single else 1.0e-9), name
+
+
 # ------------------------------------------------------- stochastic MU NMF -----
 def test_nmf_minibatch_all_cases(golden_dir):
     from oracle import nmf_minibatch as omb
