@@ -60,10 +60,13 @@ struct GemmProblem {
 // PIPE_ = 1: the per-block barrier sits between the MFMA groups of a K block (operands of the
 // last group already in registers, first group of the next block prefetched right after the
 // barrier), so no wave leaves the barrier with nothing to feed the matrix pipe.
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int PIPE_ = 0>
+// MF_ = 32: v_mfma_f32_32x32x2_f32; MF_ = 16: v_mfma_f32_16x16x4_f32 (same flop rate, same LDS
+// read volume and accumulator count; the chip may hold a different clock on it, guide rule 28).
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int PIPE_ = 0, int MF_ = 32>
 struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_;
     static constexpr int PIPE = PIPE_;
+    static constexpr int MF = MF_;
     static constexpr int NWAVES = (BM_ / WM_) * (BN_ / WN_);
     static constexpr int NTHREADS = 64 * NWAVES;
 };
@@ -84,14 +87,23 @@ struct epi_mode { static constexpr int value = 0; };
 template <class E>
 struct epi_mode<E, decltype((void)E::kMode)> { static constexpr int value = E::kMode; };
 
-template <int LAY, int ROWS, int BK, int NT = 256>
+template <int LAY, int ROWS, int BK, int NT = 256, int MF = 32>
 struct PanelGeom {
     static constexpr int STRIDE = (LAY == KMAJOR) ? BK : ROWS;
     static constexpr int CHUNKS = BK / 4;   // 16-byte chunks per KMAJOR row
     static constexpr int RPB = 64 / BK;     // KMAJOR rows per 256-byte bank row
     static_assert(BK <= 64 && 64 % BK == 0, "BK must divide 64");
+    static_assert(MF == 32 || BK == 16, "the 16x16x4 lane map is laid out for BK = 16");
     // float offset of chunk q (4 floats) of row r in the swizzled KMAJOR image
     __device__ static __forceinline__ int kchunk(int r, int q) {
+        if (MF == 16) {
+            // 16x16x4 map: lane = 16 * q + row (k quarter q of a 16-row fragment).  The four rows
+            // r, r+4, r+8, r+12 share a 64-byte column of the 256-byte bank row; XOR with
+            // f(r/4 % 4), f = (0, 2, 3, 1), sends the 16 lanes of every ds_read_b128 group to 16
+            // distinct 16-byte slots (checked against the group lists of MI355X_MICROARCH.md).
+            const int f = (0x78 >> (2 * ((r >> 2) & 3))) & 3;      // 0b01'11'10'00 -> f = 0, 2, 3, 1
+            return r * BK + ((q ^ f) << 2);
+        }
         return r * BK + ((q ^ ((r / RPB) % CHUNKS)) << 2);
     }
     static constexpr int LINES = (LAY == KMAJOR) ? ROWS : BK;
@@ -135,7 +147,7 @@ __device__ __forceinline__ void panel_gload(f32x4 (&r)[F4],
     }
 }
 
-template <int LAY, int ROWS, int BK, int NT, int F4>
+template <int LAY, int ROWS, int BK, int NT, int MF = 32, int F4>
 __device__ __forceinline__ void panel_lds_store(float* s, const f32x4 (&r)[F4], int tid) {
     static_assert(F4 == PanelGeom<LAY, ROWS, BK, NT>::F4, "register panel size");
     constexpr int STRIDE = PanelGeom<LAY, ROWS, BK>::STRIDE;
@@ -144,7 +156,7 @@ __device__ __forceinline__ void panel_lds_store(float* s, const f32x4 (&r)[F4], 
         const int idx = tid + i * NT;
         if (LAY == KMAJOR) {
             const int row = idx / (BK / 4), q = idx % (BK / 4);
-            *reinterpret_cast<f32x4*>(s + PanelGeom<LAY, ROWS, BK>::kchunk(row, q)) = r[i];
+            *reinterpret_cast<f32x4*>(s + PanelGeom<LAY, ROWS, BK, 256, MF>::kchunk(row, q)) = r[i];
         } else {
             const int kr = idx / (ROWS / 4), rq = (idx % (ROWS / 4)) * 4;
             *reinterpret_cast<f32x4*>(s + kr * STRIDE + rq) = r[i];
@@ -169,12 +181,32 @@ __device__ __forceinline__ f32x4 panel_frag(const float* s, int row, int c, int 
     }
 }
 
+// 16x16x4 form: fragment of a 16-row group for the 4 MFMA steps of one 16-deep K block.  Lane
+// (l15 = lane & 15, q = lane >> 4) gets element (row, k = 4q + j) in [j]: step j consumes
+// k = {j, 4 + j, 8 + j, 12 + j} on the four lane quarters.
+template <int LAY, int ROWS, int BK>
+__device__ __forceinline__ f32x4 panel_frag16(const float* s, int row, int q) {
+    constexpr int STRIDE = PanelGeom<LAY, ROWS, BK>::STRIDE;
+    if (LAY == KMAJOR) {
+        return *reinterpret_cast<const f32x4*>(s + PanelGeom<LAY, ROWS, BK, 256, 16>::kchunk(row, q));
+    } else {
+        f32x4 v;
+        const float* t = s + (4 * q) * STRIDE + row;
+        v[0] = t[0];
+        v[1] = t[STRIDE];
+        v[2] = t[2 * STRIDE];
+        v[3] = t[3 * STRIDE];
+        return v;
+    }
+}
+
 template <class Cfg, int ALAY, int BLAY, bool EDGE, class Epi>
 __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(GemmProblem p, Epi epi) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, WM = Cfg::WM, WN = Cfg::WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = Cfg::NTHREADS;
+    constexpr int MF = Cfg::MF;
     static_assert(BK % 8 == 0, "BK multiple of 8");
     typedef PanelGeom<ALAY, BM, BK, NT> GA;
     typedef PanelGeom<BLAY, BN, BK, NT> GB;
@@ -228,6 +260,70 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
         ncol_end = p.N;
     }
 
+    if constexpr (MF == 16) {
+        // ---- v_mfma_f32_16x16x4_f32 form: (WM/16) x (WN/16) accumulators of 4 registers ----
+        static_assert(BK == 16 && Cfg::PIPE == 0, "16x16x4 form: BK = 16, plain schedule");
+        static_assert(epi_mode<Epi>::value == 0, "16x16x4 form: real epilogues only");
+        constexpr int T16M = WM / 16, T16N = WN / 16;
+        const int l15 = lane & 15, q = lane >> 4;
+        f32x4 acc16[T16M][T16N];
+#pragma unroll
+        for (int i = 0; i < T16M; ++i)
+#pragma unroll
+            for (int j = 0; j < T16N; ++j) acc16[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 ra[GA::F4], rb[GB::F4];
+        const int nkb = (kend - kbeg + BK - 1) / BK;
+        if (nkb > 0) {
+            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+            panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
+            panel_lds_store<ALAY, BM, BK, NT, MF>(sA0, ra, tid);
+            panel_lds_store<BLAY, BN, BK, NT, MF>(sB0, rb, tid);
+        }
+        __syncthreads();
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int cur = kb & 1;
+            const float* sA = sA0 + cur * GA::ELEMS;
+            const float* sB = sB0 + cur * GB::ELEMS;
+            const bool more = (kb + 1) < nkb;
+            if (more) {
+                const int k0 = kbeg + (kb + 1) * BK;
+                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+                panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+            }
+            f32x4 fa[T16M], fb[T16N];
+#pragma unroll
+            for (int i = 0; i < T16M; ++i) fa[i] = panel_frag16<ALAY, BM, BK>(sA, wm * WM + i * 16 + l15, q);
+#pragma unroll
+            for (int j = 0; j < T16N; ++j) fb[j] = panel_frag16<BLAY, BN, BK>(sB, wn * WN + j * 16 + l15, q);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int i = 0; i < T16M; ++i)
+#pragma unroll
+                    for (int j = 0; j < T16N; ++j)
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][st], fb[j][st], acc16[i][j],
+                                                                           0, 0, 0);
+            if (more) {
+                panel_lds_store<ALAY, BM, BK, NT, MF>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
+                panel_lds_store<BLAY, BN, BK, NT, MF>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
+            }
+            __syncthreads();
+        }
+        // C layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+        for (int i = 0; i < T16M; ++i)
+#pragma unroll
+            for (int j = 0; j < T16N; ++j) {
+                const int col = n0 + wn * WN + j * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * WM + i * 16 + 4 * q + r;
+                    if (!EDGE || (row < p.M && col < ncol_end)) epi(row, col, acc16[i][j][r], split);
+                }
+            }
+        return;
+    }
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -242,12 +338,55 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     if (nkb > 0) {
         panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
         panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
-        panel_lds_store<ALAY, BM, BK, NT>(sA0, ra, tid);
-        panel_lds_store<BLAY, BN, BK, NT>(sB0, rb, tid);
+        panel_lds_store<ALAY, BM, BK, NT, MF>(sA0, ra, tid);
+        panel_lds_store<BLAY, BN, BK, NT, MF>(sB0, rb, tid);
     }
     __syncthreads();
 
-    if constexpr (Cfg::PIPE == 0) {
+    if constexpr (Cfg::PIPE == 2) {
+        // All fragment reads of a K block are issued right after the barrier, ahead of its first
+        // MFMA (the compiler's own schedule re-uses one register set and reads group c + 1 only
+        // when group c has been issued: with the four waves of a SIMD phase-locked by the barrier
+        // that leaves the matrix pipe idle for one LDS round trip per group).
+        constexpr int NC = BK / 8;
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int cur = kb & 1;
+            const float* sA = sA0 + cur * GA::ELEMS;
+            const float* sB = sB0 + cur * GB::ELEMS;
+            const bool more = (kb + 1) < nkb;
+            f32x4 fa[NC][TM], fb[NC][TN];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[c][i] = panel_frag<ALAY, BM, BK>(sA, wm * WM + i * 32 + l31, c, h);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[c][j] = panel_frag<BLAY, BN, BK>(sB, wn * WN + j * 32 + l31, c, h);
+            }
+            if (more) {  // next block's global loads, behind the LDS reads in issue order
+                const int k0 = kbeg + (kb + 1) * BK;
+                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+                panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][s], fb[c][j][s],
+                                                                             acc[i][j], 0, 0, 0);
+            if (more) {
+                panel_lds_store<ALAY, BM, BK, NT, MF>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
+                panel_lds_store<BLAY, BN, BK, NT, MF>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
+            }
+            __syncthreads();
+        }
+    } else if constexpr (Cfg::PIPE == 0) {
         for (int kb = 0; kb < nkb; ++kb) {
             const int cur = kb & 1;
             const float* sA = sA0 + cur * GA::ELEMS;
@@ -277,8 +416,8 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
                                                                              acc[i][j], 0, 0, 0);
             }
             if (more) {
-                panel_lds_store<ALAY, BM, BK, NT>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
-                panel_lds_store<BLAY, BN, BK, NT>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
+                panel_lds_store<ALAY, BM, BK, NT, MF>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
+                panel_lds_store<BLAY, BN, BK, NT, MF>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
             }
             __syncthreads();
         }
@@ -318,8 +457,8 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
                         nb[j] = panel_frag<BLAY, BN, BK>(sB, wn * WN + j * 32 + l31, c + 1, h);
                 } else {
                     if (more) {
-                        panel_lds_store<ALAY, BM, BK, NT>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
-                        panel_lds_store<BLAY, BN, BK, NT>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
+                        panel_lds_store<ALAY, BM, BK, NT, MF>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
+                        panel_lds_store<BLAY, BN, BK, NT, MF>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
                     }
                     __syncthreads();
                     if ((kb + 2) < nkb) {

@@ -69,6 +69,21 @@ typedef TileCfg<256, 256, 16, 64, 64, 1, 1> Cfg16wPipe;    // 12: 16 waves, 256x
 typedef TileCfg<128, 128, 16, 64, 64, 2, 1> CfgLargePipe;  // 13: 4 waves, 128x128, same
 typedef TileCfg<256, 256, 32, 64, 64, 1, 1> Cfg16wDeepPipe; // 14: 16 waves, BK = 32, same
 
+// small tiles with deep K blocks: shard-size products (few rows per GPU) and the K = 256 D-side products
+typedef TileCfg<64, 128, 64, 32, 32, 2> CfgRow64x128d64;   // 15: 8 waves of 32x32, BK = 64 (96 KiB LDS)
+typedef TileCfg<64, 128, 32, 32, 32, 2> CfgRow64x128d32;   // 16: same, BK = 32 (48 KiB)
+typedef TileCfg<64, 64, 64, 32, 32, 1> CfgSmallD64;        // 17: 4 waves of 32x32, BK = 64 (64 KiB)
+typedef TileCfg<64, 64, 32, 32, 32, 2> CfgSmallD32;        // 18: 4 waves, BK = 32 (32 KiB)
+typedef TileCfg<128, 64, 64, 32, 32, 2> CfgRow128x64d64;   // 19: 8 waves of 32x32 (4 x 2), BK = 64
+typedef TileCfg<128, 128, 32, 32, 64, 2> CfgLarge8wD32;    // 20: 8 waves of 32x64, BK = 32 (64 KiB)
+typedef TileCfg<128, 128, 64, 32, 64, 2> CfgLarge8wD64;    // 21: 8 waves of 32x64, BK = 64 (128 KiB)
+typedef TileCfg<64, 256, 32, 32, 64, 2> CfgRow64x256d32;   // 22: 8 waves of 32x64 (2 x 4), BK = 32 (80 KiB)
+// measured and NOT adopted (kept reachable for A/B runs, tools/mf16_ab.sh, tools/ahead_ab.sh):
+typedef TileCfg<256, 256, 16, 64, 64, 1, 0, 16> Cfg16wMf16;    // 23: 256x256 / 16 waves on v_mfma_f32_16x16x4_f32
+typedef TileCfg<128, 128, 16, 64, 64, 2, 0, 16> CfgLargeMf16;  // 24: 128x128 / 4 waves on 16x16x4
+typedef TileCfg<256, 256, 16, 64, 64, 1, 2> Cfg16wAhead;       // 25: all fragment reads of a K block up front
+typedef TileCfg<128, 128, 16, 64, 64, 2, 2> CfgLargeAhead;     // 26: same, 128x128 / 4 waves
+
 template <class Cfg, int FORM, class Epi>
 hipError_t hook_cfg(hipStream_t st, const GemmArgs<float>& a, const Epi& epi) {
     GemmProblem p;
@@ -127,6 +142,18 @@ hipError_t gemm_hook_launch(hipStream_t st, const GemmArgs<T>& a, int tile, cons
             case 12: return hook_cfg<Cfg16wPipe, FORM>(st, a, epi);
             case 13: return hook_cfg<CfgLargePipe, FORM>(st, a, epi);
             case 14: return hook_cfg<Cfg16wDeepPipe, FORM>(st, a, epi);
+            case 15: return hook_cfg<CfgRow64x128d64, FORM>(st, a, epi);
+            case 16: return hook_cfg<CfgRow64x128d32, FORM>(st, a, epi);
+            case 17: return hook_cfg<CfgSmallD64, FORM>(st, a, epi);
+            case 18: return hook_cfg<CfgSmallD32, FORM>(st, a, epi);
+            case 19: return hook_cfg<CfgRow128x64d64, FORM>(st, a, epi);
+            case 20: return hook_cfg<CfgLarge8wD32, FORM>(st, a, epi);
+            case 21: return hook_cfg<CfgLarge8wD64, FORM>(st, a, epi);
+            case 22: return hook_cfg<CfgRow64x256d32, FORM>(st, a, epi);
+            case 23: return hook_cfg<Cfg16wMf16, FORM>(st, a, epi);
+            case 24: return hook_cfg<CfgLargeMf16, FORM>(st, a, epi);
+            case 25: return hook_cfg<Cfg16wAhead, FORM>(st, a, epi);
+            case 26: return hook_cfg<CfgLargeAhead, FORM>(st, a, epi);
             default: break;
         }
     }
