@@ -380,6 +380,24 @@ struct EpiMulMask {
     }
 };
 
+// out = acc * mask for a BINARY mask handed over as row bits (see epi_rowbits in gemm_mfma_f32.hpp):
+// the factor is exactly 1.0f or 0.0f and the product is formed as in EpiMulMask (so NaN / Inf / -0
+// behave as the reference's  f * mask).  float only (the fp32 MFMA core implements the protocol).
+struct EpiMulMaskBits {
+    static constexpr bool kRowBits = true;
+    const uint32_t* bits;   // [(rows + 31) / 32][ld_bits]
+    long ld_bits;
+    float* out;
+    long ld_out;
+    __device__ __forceinline__ uint32_t load_bits(int row0, int col) const {
+        return bits[(long)(row0 >> 5) * ld_bits + col];
+    }
+    __device__ __forceinline__ void with_bit(int r, int c, float v, uint32_t bit, int) const {
+        out[(long)r * ld_out + c] = v * (bit ? 1.0f : 0.0f);
+    }
+    __device__ __forceinline__ void operator()(int, int, float, int) const {}
+};
+
 // KL ratio: out = (y [* mask]) / (acc + 1e-15)   (grads.py:145-149,154-158)
 template <class T>
 struct EpiKlRatio {

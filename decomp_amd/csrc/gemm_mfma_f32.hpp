@@ -87,6 +87,18 @@ struct epi_mode { static constexpr int value = 0; };
 template <class E>
 struct epi_mode<E, decltype((void)E::kMode)> { static constexpr int value = E::kMode; };
 
+// Epilogue functors may carry `static constexpr bool kRowBits = true`: a per-element 0/1 factor
+// packed 32 ROWS to a word (word (row / 32, col) holds rows 32*(row/32) .. +31 of column col).
+// The kernel then fetches, BEFORE its main loop, the one word per 32x32 accumulator a lane needs
+// (its column, the accumulator's 32 rows: TM x TN registers) and hands every element its bit:
+//   uint32_t load_bits(int row0 /* multiple of 32 */, int col)       epi.with_bit(row, col, v, bit, split)
+// so that the epilogue issues no loads of the factor at all (a float mask costs one 4-byte load per
+// element there, in batches of dependent round trips: registers are full).
+template <class E, class = void>
+struct epi_rowbits { static constexpr bool value = false; };
+template <class E>
+struct epi_rowbits<E, decltype((void)E::kRowBits)> { static constexpr bool value = E::kRowBits; };
+
 template <int LAY, int ROWS, int BK, int NT = 256, int MF = 32>
 struct PanelGeom {
     static constexpr int STRIDE = (LAY == KMAJOR) ? BK : ROWS;
@@ -263,7 +275,7 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     if constexpr (MF == 16) {
         // ---- v_mfma_f32_16x16x4_f32 form: (WM/16) x (WN/16) accumulators of 4 registers ----
         static_assert(BK == 16 && Cfg::PIPE == 0, "16x16x4 form: BK = 16, plain schedule");
-        static_assert(epi_mode<Epi>::value == 0, "16x16x4 form: real epilogues only");
+        static_assert(epi_mode<Epi>::value == 0 && !epi_rowbits<Epi>::value, "16x16x4 form: plain real epilogues only");
         constexpr int T16M = WM / 16, T16N = WN / 16;
         const int l15 = lane & 15, q = lane >> 4;
         f32x4 acc16[T16M][T16N];
@@ -322,6 +334,19 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
                 }
             }
         return;
+    }
+
+    constexpr bool ROWBITS = epi_rowbits<Epi>::value;
+    uint32_t rbits[TM][TN];
+    if constexpr (ROWBITS) {
+        static_assert(epi_mode<Epi>::value == 0, "row-bit factors: real epilogues only");
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int brow = m0 + wm * WM + i * 32, bcol = n0 + wn * WN + j * 32 + l31;
+                rbits[i][j] = (!EDGE || (brow < p.M && bcol < ncol_end)) ? epi.load_bits(brow, bcol) : 0u;
+            }
     }
 
     f32x16 acc[TM][TN];
@@ -511,8 +536,12 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
             if constexpr (MODE == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (!EDGE || (row < p.M && col < ncol_end)) epi(row, col, acc[i][j][r], split);
+                    const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int row = m0 + wm * WM + i * 32 + rin;
+                    if (!EDGE || (row < p.M && col < ncol_end)) {
+                        if constexpr (ROWBITS) epi.with_bit(row, col, acc[i][j][r], (rbits[i][j] >> rin) & 1u, split);
+                        else epi(row, col, acc[i][j][r], split);
+                    }
                 }
             } else if constexpr (MODE == 1) {
 #pragma unroll

@@ -113,6 +113,33 @@ __global__ void __launch_bounds__(256) mul_mask_kernel(const T* __restrict__ a,
     }
 }
 
+// Row-bit image of a mask (EpiMulMaskBits): word (g, c) holds (mask[32 g + b, c] != 0) in bit b.
+// *not_binary is set when some entry is neither 0 nor 1 (the bit image then cannot stand in for the
+// mask).  One thread per (row group, column): the 32 row reads of a wave are 256-byte coalesced rows.
+template <class R>
+__global__ void __launch_bounds__(256) mask_rowbits_kernel(const R* __restrict__ mask, long rows, long cols,
+                                                           uint32_t* __restrict__ bits,
+                                                           int* __restrict__ not_binary) {
+    const long groups = (rows + 31) / 32;
+    const long n = groups * cols;
+    bool bad = false;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const long g = i / cols, c = i - g * cols;
+        uint32_t w = 0;
+#pragma unroll 8
+        for (int b = 0; b < 32; ++b) {
+            const long r = g * 32 + b;
+            if (r < rows) {
+                const R m = mask[r * cols + c];
+                if (m != R(0)) w |= (1u << b);
+                if (m != R(0) && m != R(1)) bad = true;
+            }
+        }
+        bits[i] = w;
+    }
+    if (bad) atomicOr(not_binary, 1);
+}
+
 // out = cur * max(num, 0) / max(den, eps)   (grads.py:84,93), arbitrary leading dims.
 // den_bcast: 0 = full [rows, cols]; 1 = one value per row (den[row]); 2 = one per column.
 template <class T>

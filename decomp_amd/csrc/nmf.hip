@@ -39,6 +39,11 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     plan.add<T>((size_t)K * F);   // second D buffer
     plan.add<T>((size_t)N * K);   // second x buffer
     plan.add<T>(2);               // max|dD| of the two iterations in flight
+    const bool want_bits = masked && std::is_same<T, float>::value && lik == DCP_LIK_L2;
+    if (want_bits) {
+        plan.add<uint32_t>(mask_bits_words(N, F));
+        plan.add<int>(4);
+    }
     if (want_resid) {
         if (gram) plan.add<T>((size_t)N * F);
         plan.add<double>(resid_blocks);
@@ -53,6 +58,13 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     T* D2 = ws_alloc<T>(h, (size_t)K * F);
     T* X2 = ws_alloc<T>(h, (size_t)N * K);
     T* maxdiff_dev = ws_alloc<T>(h, 2);
+    uint32_t* mbits = nullptr;
+    int* mflag = nullptr;
+    if (want_bits) {
+        mbits = ws_alloc<uint32_t>(h, mask_bits_words(N, F));
+        mflag = ws_alloc<int>(h, 4);
+        if (!mbits || !mflag) return fail(h, DCP_ERR_INTERNAL, "nmf workspace plan mismatch");
+    }
     T* resid_tmp = nullptr;
     double* resid_part = nullptr;
     if (want_resid) {
@@ -75,10 +87,10 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
 
     const T* Ypre = Y;
     if (masked) {  // y * mask is loop invariant (grads.py:114,124 recompute it every call)
-        hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for(N * F)), dim3(256), 0, h->stream, Y,
-                           mask, (long)N, (long)F, (long)F, ws.Ym);
-        DCP_HIP_OK(h, hipGetLastError());
+        int binary = 0;
+        DCP_TRY(nmf_mask_prepare<T>(h, Y, mask, N, F, ws.Ym, mbits, mflag, &binary));
         Ypre = ws.Ym;
+        if (binary) ws.mbits = mbits;
     }
     DCP_HIP_OK(h, hipMemsetAsync(maxdiff_dev, 0, 2 * sizeof(T), h->stream));
 
@@ -163,6 +175,40 @@ int nmf_mu_stats_api(dcp_handle* h, const T* Y, const T* mask, const T* X, T* X_
         Ypre = ws.Ym;
     }
     return nmf_stats<T>(h, Ypre, mask, X, X_out, D, s, stats, ws);
+}
+
+// dcp_nmf_mu_stats_* with the loop-invariant mask work done once by dcp_nmf_mask_prepare_*.
+template <class T>
+int nmf_mu_stats_prepared_api(dcp_handle* h, const T* Ym, const T* mask, const uint32_t* bits, const T* X,
+                              T* X_out, const T* D, int64_t N, int64_t F, int64_t K, int lik, T* stats) {
+    DCP_TRY(check_nmf_args(h, Ym, X, D, N, F, K, lik));
+    if (!stats || !X_out || !mask) return fail(h, DCP_ERR_INVALID, "stats / X_out / mask is null");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    NmfShape<T> s{N, F, K, lik, true};
+    WsPlan plan;
+    nmf_plan_stats(plan, s, false);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    NmfStatsWs<T> ws;
+    DCP_TRY(nmf_carve_stats(h, ws, s, false));
+    ws.mbits = bits;
+    return nmf_stats<T>(h, Ym, mask, X, X_out, D, s, stats, ws);
+}
+
+template <class T>
+int nmf_mask_prepare_api(dcp_handle* h, const T* Y, const T* mask, int64_t N, int64_t F, T* Ym,
+                         uint32_t* bits, int* binary) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!Y || !mask || !Ym || !binary) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (N <= 0 || F <= 0) return fail(h, DCP_ERR_INVALID, "sizes must be positive");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    WsPlan plan;
+    plan.add<int>(4);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    int* flag = ws_alloc<int>(h, 4);
+    if (!flag) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
+    return nmf_mask_prepare<T>(h, Y, mask, N, F, Ym, bits, flag, binary);
 }
 
 template <class T>
@@ -392,6 +438,25 @@ int dcp_nmf_mu_stats_f64(dcp_handle* h, const double* Y, const double* mask, con
                          double* X_out, const double* D, int64_t N, int64_t F, int64_t K,
                          int likelihood, double* stats) {
     return nmf_mu_stats_api<double>(h, Y, mask, X, X_out, D, N, F, K, likelihood, stats);
+}
+int dcp_nmf_mask_prepare_f32(dcp_handle* h, const float* Y, const float* mask, int64_t N, int64_t F,
+                             float* Ym, uint32_t* bits, int* binary) {
+    return nmf_mask_prepare_api<float>(h, Y, mask, N, F, Ym, bits, binary);
+}
+int dcp_nmf_mask_prepare_f64(dcp_handle* h, const double* Y, const double* mask, int64_t N, int64_t F,
+                             double* Ym, uint32_t* bits, int* binary) {
+    return nmf_mask_prepare_api<double>(h, Y, mask, N, F, Ym, bits, binary);
+}
+int64_t dcp_nmf_mask_bits_words(int64_t N, int64_t F) { return (int64_t)mask_bits_words(N, F); }
+int dcp_nmf_mu_stats_prepared_f32(dcp_handle* h, const float* Ym, const float* mask, const uint32_t* bits,
+                                  const float* X, float* X_out, const float* D, int64_t N, int64_t F,
+                                  int64_t K, int likelihood, float* stats) {
+    return nmf_mu_stats_prepared_api<float>(h, Ym, mask, bits, X, X_out, D, N, F, K, likelihood, stats);
+}
+int dcp_nmf_mu_stats_prepared_f64(dcp_handle* h, const double* Ym, const double* mask, const uint32_t* bits,
+                                  const double* X, double* X_out, const double* D, int64_t N, int64_t F,
+                                  int64_t K, int likelihood, double* stats) {
+    return nmf_mu_stats_prepared_api<double>(h, Ym, mask, bits, X, X_out, D, N, F, K, likelihood, stats);
 }
 int dcp_nmf_mu_update_f32(dcp_handle* h, const float* stats, const float* D, float* D_new,
                           int64_t F, int64_t K, int likelihood, int masked, float* maxdiff_dev,

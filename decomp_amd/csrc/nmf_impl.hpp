@@ -49,6 +49,9 @@ struct NmfStatsWs {
     T* vecK = nullptr;    // [K]     KL: colsum(D) / colsum(x)
     T* part = nullptr;    // column-sum partials
     size_t slab_count = 0;
+    // float + 0/1 mask: its row-bit image (mask_rowbits_kernel); the forward product then multiplies
+    // by bits fetched ahead of its main loop instead of loading the float mask in its epilogue
+    const uint32_t* mbits = nullptr;
 };
 
 // Split-K plan of the x-update GEMM (Y D^T, [N,F]x[K,F]): only when the row tiles alone
@@ -175,9 +178,15 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
         ProfScope ps(h, DCP_PROF_FWD);
         GemmArgs<T> fa;
         fa.A = X; fa.lda = K; fa.B = D; fa.ldb = F; fa.M = N; fa.N = F; fa.K = K;
-        if (s.lik == DCP_LIK_L2)   // f = (x D) o M                 (grads.py:113,123)
+        if (s.lik == DCP_LIK_L2) {  // f = (x D) o M                 (grads.py:113,123)
+            if constexpr (std::is_same<T, float>::value) {
+                if (w.mbits != nullptr) {
+                    DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, fa, EpiMulMaskBits{w.mbits, (long)F, w.f, (long)F})));
+                    return DCP_OK;
+                }
+            }
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, fa, EpiMulMask<T>{mask, F, w.f, F})));
-        else                       // r = (Y o M) / (x D + eps)     (grads.py:145-149)
+        } else                       // r = (Y o M) / (x D + eps)     (grads.py:145-149)
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, fa, EpiKlRatio<T>{Ypre, F, nullptr, 0, w.f, F})));
         return DCP_OK;
     };
@@ -352,5 +361,34 @@ inline int nmf_residual(dcp_handle* h, const T* Y, const T* mask, const T* X, co
     DCP_LAUNCH_OK(h, hipGetLastError());
     return DCP_OK;
 }
+
+}  // namespace dcp
+
+namespace dcp {
+
+// Loop-invariant part of a masked solve: Ym = Y o M (grads.py:114,124 recompute it every call) and,
+// for float, the row-bit image of a 0/1 mask.  *binary (host) tells whether `bits` may stand in for
+// the mask.  Synchronises the stream once (the flag read-back).
+template <class T>
+inline int nmf_mask_prepare(dcp_handle* h, const T* Y, const T* mask, int64_t N, int64_t F, T* Ym,
+                            uint32_t* bits, int* flag_dev, int* binary) {
+    hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for(N * F)), dim3(256), 0, h->stream, Y, mask,
+                       (long)N, (long)F, (long)F, Ym);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    *binary = 0;
+    if (!std::is_same<T, float>::value || bits == nullptr) return DCP_OK;
+    void* hostv = nullptr;
+    DCP_TRY(host_scratch(h, 64, &hostv));
+    DCP_HIP_OK(h, hipMemsetAsync(flag_dev, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL((mask_rowbits_kernel<T>), dim3(grid_for(((N + 31) / 32) * F)), dim3(256), 0,
+                       h->stream, mask, (long)N, (long)F, bits, flag_dev);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    DCP_HIP_OK(h, hipMemcpyAsync(hostv, flag_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    *binary = (*reinterpret_cast<int*>(hostv) == 0) ? 1 : 0;
+    return DCP_OK;
+}
+
+inline size_t mask_bits_words(int64_t N, int64_t F) { return (size_t)((N + 31) / 32) * (size_t)F; }
 
 }  // namespace dcp

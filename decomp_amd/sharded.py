@@ -37,13 +37,31 @@ class HipStepBackend(object):
         self.maxdiff = torch.zeros((2,), dtype=D.dtype, device=D.device)
         self._host = torch.zeros((2,), dtype=D.dtype).pin_memory()
         self._events = [None, None]
+        self._ym = self._bits = None
+        if mask is not None:
+            # loop-invariant mask work, once per run: y o mask and (float32, 0/1 mask) its row bits
+            h = _arrays.lib_handle(D)[1]
+            self._ym = torch.empty_like(y)
+            words = lib.dcp_nmf_mask_bits_words(self.N, self.F)
+            bits = torch.empty((words,), dtype=torch.int32, device=D.device) if self.sfx == 'f32' else None
+            binary = ctypes.c_int(0)
+            fn = getattr(lib, 'dcp_nmf_mask_prepare_' + self.sfx)
+            _hip.check(h, fn(h, _arrays.ptr(y), _arrays.ptr(mask), self.N, self.F, _arrays.ptr(self._ym),
+                             _arrays.ptr(bits), ctypes.byref(binary)), 'dcp_nmf_mask_prepare')
+            self._bits = bits if binary.value else None
 
     def local_stats(self, D):
         lib, h = _arrays.lib_handle(D)
-        fn = getattr(lib, 'dcp_nmf_mu_stats_' + self.sfx)
-        _hip.check(h, fn(h, _arrays.ptr(self.y), _arrays.ptr(self.mask), _arrays.ptr(self.x),
-                         _arrays.ptr(self._x_other), _arrays.ptr(D), self.N, self.F, self.K,
-                         self.lik, _arrays.ptr(self.stats)), 'dcp_nmf_mu_stats')
+        if self.mask is not None:
+            fn = getattr(lib, 'dcp_nmf_mu_stats_prepared_' + self.sfx)
+            _hip.check(h, fn(h, _arrays.ptr(self._ym), _arrays.ptr(self.mask), _arrays.ptr(self._bits),
+                             _arrays.ptr(self.x), _arrays.ptr(self._x_other), _arrays.ptr(D), self.N,
+                             self.F, self.K, self.lik, _arrays.ptr(self.stats)), 'dcp_nmf_mu_stats_prepared')
+        else:
+            fn = getattr(lib, 'dcp_nmf_mu_stats_' + self.sfx)
+            _hip.check(h, fn(h, _arrays.ptr(self.y), None, _arrays.ptr(self.x),
+                             _arrays.ptr(self._x_other), _arrays.ptr(D), self.N, self.F, self.K,
+                             self.lik, _arrays.ptr(self.stats)), 'dcp_nmf_mu_stats')
         self.x, self._x_other = self._x_other, self.x
         return self.stats
 

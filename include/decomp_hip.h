@@ -162,6 +162,25 @@ int dcp_nmf_mu_stats_f32(dcp_handle* h, const float* Y, const float* mask, const
 int dcp_nmf_mu_stats_f64(dcp_handle* h, const double* Y, const double* mask, const double* X,
                          double* X_out, const double* D, int64_t N, int64_t F, int64_t K,
                          int likelihood, double* stats);
+/* Loop-invariant mask work of a masked run, done ONCE instead of in every dcp_nmf_mu_stats_* call
+ * (grads.py:114,124 recompute y * mask per gradient): Ym[N,F] = Y o mask, and -- float32 only, `bits`
+ * non-NULL -- the row-bit image of the mask (dcp_nmf_mask_bits_words(N, F) uint32 words: word
+ * (row / 32, col) holds mask[32 (row/32) + b, col] != 0 in bit b).  *binary (HOST) = 1 when every mask
+ * entry is exactly 0 or 1, i.e. when `bits` may be passed to dcp_nmf_mu_stats_prepared_* (otherwise pass
+ * NULL there).  dcp_nmf_mu_stats_prepared_*: dcp_nmf_mu_stats_* on (Ym, mask[, bits]); with bits the
+ * (x D) o M products multiply by bits fetched ahead of the GEMM main loop instead of loading the float
+ * mask in the epilogue.  Results are identical with and without bits. */
+int64_t dcp_nmf_mask_bits_words(int64_t N, int64_t F);
+int dcp_nmf_mask_prepare_f32(dcp_handle* h, const float* Y, const float* mask, int64_t N, int64_t F,
+                             float* Ym, uint32_t* bits, int* binary);
+int dcp_nmf_mask_prepare_f64(dcp_handle* h, const double* Y, const double* mask, int64_t N, int64_t F,
+                             double* Ym, uint32_t* bits, int* binary);
+int dcp_nmf_mu_stats_prepared_f32(dcp_handle* h, const float* Ym, const float* mask, const uint32_t* bits,
+                                  const float* X, float* X_out, const float* D, int64_t N, int64_t F,
+                                  int64_t K, int likelihood, float* stats);
+int dcp_nmf_mu_stats_prepared_f64(dcp_handle* h, const double* Ym, const double* mask, const uint32_t* bits,
+                                  const double* X, double* X_out, const double* D, int64_t N, int64_t F,
+                                  int64_t K, int likelihood, double* stats);
 int dcp_nmf_mu_update_f32(dcp_handle* h, const float* stats, const float* D, float* D_new,
                           int64_t F, int64_t K, int likelihood, int masked,
                           float* maxdiff_dev, float* maxdiff_next);

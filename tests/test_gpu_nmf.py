@@ -265,3 +265,56 @@ def test_sharded_loop_over_rccl_world1():
     assert p.exitcode == 0
     assert it == it1
     assert np.array_equal(D, D1) and np.array_equal(x, x1)
+
+
+@pytest.mark.parametrize('shape', [(1000, 1200, 24), (4096, 1024, 256), (333, 77, 5)])
+def test_mask_row_bits_identical_to_float_mask_and_fallback(shape):
+    """The masked forward product multiplies by row bits fetched ahead of the GEMM main loop when the
+    float32 mask is 0/1 (dcp_nmf_mask_prepare_*): results must be BIT-identical to the float-mask
+    epilogue; a fractional mask must report binary = 0 and match the oracle through the float path."""
+    import ctypes
+    import torch
+    from decomp_amd import _arrays, _hip
+    from oracle import nmf as onmf, common
+    N, F, K = shape
+    rng = np.random.RandomState(N)
+    xt = np.maximum(rng.randn(N, K), 0)
+    Dt = np.maximum(rng.randn(K, F), 0)
+    y = (xt @ Dt + 0.1 * np.abs(rng.randn(N, F))).astype(np.float32)
+    D0 = common.l2_strict(np.maximum(Dt + 0.3 * rng.randn(K, F), 0.1).astype(np.float32))
+    mask = (rng.uniform(size=(N, F)) >= 0.2).astype(np.float32)
+    Y, M, D = torch.from_numpy(y).cuda(), torch.from_numpy(mask).cuda(), torch.from_numpy(D0).cuda()
+    lib, h = _arrays.lib_handle(Y)
+    W = lib.dcp_nmf_mu_stats_width(F, K, 0, 1)
+
+    def prepared(Mt, want_bits):
+        Ym = torch.empty_like(Y)
+        bits = torch.empty((lib.dcp_nmf_mask_bits_words(N, F),), dtype=torch.int32, device='cuda')
+        binary = ctypes.c_int(-1)
+        _hip.check(h, lib.dcp_nmf_mask_prepare_f32(h, _arrays.ptr(Y), _arrays.ptr(Mt), N, F, _arrays.ptr(Ym),
+                                                   _arrays.ptr(bits), ctypes.byref(binary)), 'prepare')
+        x = torch.ones((N, K), device='cuda')
+        xo, stats = torch.empty_like(x), torch.empty((K, W), device='cuda')
+        _hip.check(h, lib.dcp_nmf_mu_stats_prepared_f32(
+            h, _arrays.ptr(Ym), _arrays.ptr(Mt), _arrays.ptr(bits) if want_bits else None, _arrays.ptr(x),
+            _arrays.ptr(xo), _arrays.ptr(D), N, F, K, 0, _arrays.ptr(stats)), 'stats_prepared')
+        torch.cuda.synchronize()
+        return binary.value, xo, stats
+    b1, x1, s1 = prepared(M, True)
+    b0, x0, s0 = prepared(M, False)
+    assert b1 == 1 and b0 == 1
+    assert torch.equal(x1, x0) and torch.equal(s1, s0)
+    # the un-prepared entry point gives the same numbers
+    x = torch.ones((N, K), device='cuda')
+    xo, stats = torch.empty_like(x), torch.empty((K, W), device='cuda')
+    _hip.check(h, lib.dcp_nmf_mu_stats_f32(h, _arrays.ptr(Y), _arrays.ptr(M), _arrays.ptr(x), _arrays.ptr(xo),
+                                           _arrays.ptr(D), N, F, K, 0, _arrays.ptr(stats)), 'stats')
+    assert torch.equal(xo, x1) and torch.equal(stats, s1)
+    # fractional mask: not binary -> float path, against the oracle
+    frac = (mask * rng.uniform(0.25, 1.0, size=mask.shape)).astype(np.float32)
+    bf, xf, sf = prepared(torch.from_numpy(frac).cuda(), True)
+    assert bf == 0
+    import decomp_amd
+    it, Dg, xg = decomp_amd.nmf.solve(y, D0.copy(), tol=0.0, maxiter=4, mask=frac)
+    ito, Do, xo_ = onmf.solve(y, D0.copy(), tol=0.0, maxiter=4, mask=frac)
+    assert np.max(np.abs(Dg - Do)) < 2e-5 and np.max(np.abs(xg - xo_)) < 2e-4 * np.max(np.abs(xo_))
