@@ -14,7 +14,7 @@
 //   (2) G = P P^H  (b x b Gram, split-K GEMM over F)
 //   (3) in the block's own coefficient space (u_k = c_k . P, t_k = E_k . P):
 //           c_k = e_k - sum_{j<k} w_kj E_j ;  |u_k|^2 = c_k G c_k^H ;  E_k = c_k / sqrt(max(|u_k|^2, 1))
-//       b steps on b x b data by ONE small workgroup, in double precision
+//       b steps on b x b data by ONE small workgroup, in double precision (atom_recur_kernel)
 //   (4) D_new[block] = E . P   (GEMM [b x b].[b x F])
 // The recursion is the same arithmetic re-associated (norms through the Gram matrix); rounding
 // differs at the 1e-7 (fp32) / 1e-16 (fp64) level.  Cost per block: 2bKF + 4b^2F flops on MFMA and
@@ -117,79 +117,108 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
     return __hiloint2double(hi, lo);
 }
 
-// Step (3): ONE workgroup of 4 waves; lane i owns coefficient i, wave w takes every 4th term of
-// the two k-long sums of a step (the step is instruction-issue bound in a single wave: ~600 wide
-// instructions).  G (b x b, leading dim nb), Wl (leading dim kAtomBlkMax) -> E (leading dim nb).
-// Everything the b dependent steps touch is staged in LDS first (coalesced).
-// Two barriers per step: every wave forms c_k and E_k redundantly from the exchanged partial
-// sums, so rows E_j only ever have to be visible to the wave that consumes them (j mod 4 == w,
-// which is also the wave that stores them), and c_k is broadcast inside each wave through its own
-// LDS row -- same-wave LDS traffic is ordered, no workgroup barrier needed for either.
+// Step (3): the b dependent steps in coefficient space.  Lane i owns coefficient i.  Besides the rows
+// E_j the kernel keeps
+//     M_j = G E_j^H                                    (lane i holds (G E_j^H)[i])
+// so that BOTH sums of a step are lane-local over the already finished rows j < k:
+//     c_k[i] = delta_ik - sum_j w_kj E_j[i]            y_k[i] = (G c_k^H)[i] = G[i][k] - sum_j conj(w_kj) M_j[i]
+// and |u_k|^2 = c_k G c_k^H = Re sum_i c_k[i] y_k[i] is ONE wave reduction; then
+//     E_k = c_k / n ,  M_k = y_k / n ,  n = sqrt(max(|u_k|^2, 1))     (M_k comes for free).
+// Right-looking in sub-blocks of 8 atoms: rows k of the two LDS images start as (e_k, G[:, k]) and
+// carry the partial sums; wave 0 runs the 8 dependent steps of a sub-block (at most 7 terms each,
+// same-wave LDS traffic is ordered: no barrier inside), then ALL four waves subtract that sub-block's
+// contribution from every later row (independent rows: 8 terms each).  The sequential chain of a step
+// is thus ~8 terms + one DPP reduction + one rsqrt instead of k terms; two barriers per 8 atoms instead
+// of two per atom.  G (b x b, leading dim nb), Wl (leading dim kAtomBlkMax) -> E (leading dim nb).
+constexpr int kAtomSub = 8;
+
 template <class T>
 __global__ void __launch_bounds__(256) atom_recur_kernel(int nb, const T* __restrict__ G,
                                                          const T* __restrict__ Wl, T* __restrict__ E) {
     typedef typename wide_of<T>::type WT;
     typedef real_t<WT> WR;
     constexpr int BMAX = atom_blk<T>();
-    __shared__ WT sE[BMAX][BMAX + 1];   // rows E_j (wide type); row j is written and read by wave j % 4
-    __shared__ T sG[BMAX][BMAX + 1];    // sG[i][i'] = G[i][i']
-    __shared__ T sW[BMAX][BMAX + 1];    // sW[k][j] = w_kj
-    __shared__ WT sc[4][BMAX];          // c_k, one private copy per wave
-    __shared__ WT spart[4][BMAX];       // per-wave partial sums
-    __shared__ WR snorm[4];
+    // 2 x BMAX^2 wide elements + BMAX^2 of T (80 KiB for float): dynamic LDS, see atom_recur_lds_bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char atom_lds_raw[];
+    typedef WT (*Mat)[BMAX];
+    typedef T (*MatT)[BMAX];
+    Mat sE = reinterpret_cast<Mat>(atom_lds_raw);                              // row k: partial c_k, then E_k
+    Mat sM = reinterpret_cast<Mat>(atom_lds_raw + sizeof(WT) * BMAX * BMAX);   // row k: partial y_k, then M_k
+    MatT sW = reinterpret_cast<MatT>(atom_lds_raw + 2 * sizeof(WT) * BMAX * BMAX);   // sW[k][j] = w_kj
     const int tid = threadIdx.x, i = tid & 63, w = tid >> 6;
-    for (int e = tid; e < nb * nb; e += 256) sG[e / nb][e % nb] = G[e];
+    const bool lane_ok = i < BMAX;
+    const bool live = i < nb;
     for (int e = tid; e < nb * BMAX; e += 256) sW[e / BMAX][e % BMAX] = Wl[(e / BMAX) * kAtomBlkMax + (e % BMAX)];
-    __syncthreads();
-    const int il = i < BMAX ? i : 0;
-    const bool live = i < BMAX;
-    for (int k = 0; k < nb; ++k) {
-        // c_k[i] = delta_ik - sum_{j<k} w_kj E_j[i]      (wave w: j = w, w+4, ...)
-        // (LDS operands fetched four at a time: the loops are LDS-latency bound otherwise)
-        WT acc = zero_of<WT>();
-        {
-            int j = w;
-            for (; j + 12 < k; j += 16) {
-                const T w0 = sW[k][j], w1 = sW[k][j + 4], w2 = sW[k][j + 8], w3 = sW[k][j + 12];
-                const WT e0 = sE[j][il], e1 = sE[j + 4][il], e2 = sE[j + 8][il], e3 = sE[j + 12][il];
-                acc = madd(acc, widen(w0), e0);
-                acc = madd(acc, widen(w1), e1);
-                acc = madd(acc, widen(w2), e2);
-                acc = madd(acc, widen(w3), e3);
-            }
-            for (; j < k; j += 4) acc = madd(acc, widen(sW[k][j]), sE[j][il]);
-        }
-        if (live) spart[w][i] = acc;
-        __syncthreads();                                        // barrier 1: partial sums
-        WT c = sub((i == k) ? from_real<WT>(WR(1)) : zero_of<WT>(),
-                   add(add(spart[0][il], spart[1][il]), add(spart[2][il], spart[3][il])));
-        if (i >= nb || i > k) c = zero_of<WT>();   // support of c_k is i <= k
-        if (live) sc[w][i] = c;                    // this wave's own copy (same-wave LDS order)
-        __builtin_amdgcn_wave_barrier();
-        // |u_k|^2 = sum_{i,i'} c_i conj(c_i') G_ii'      (wave w: i' = w, w+4, ...)
-        WT v = zero_of<WT>();
-        if (i <= k && i < nb) {
-            int ip = w;
-            for (; ip + 12 <= k; ip += 16) {
-                const WT a0 = sc[w][ip], a1 = sc[w][ip + 4], a2 = sc[w][ip + 8], a3 = sc[w][ip + 12];
-                const T g0 = sG[il][ip], g1 = sG[il][ip + 4], g2 = sG[il][ip + 8], g3 = sG[il][ip + 12];
-                v = madd(v, conj_of(a0), widen(g0));
-                v = madd(v, conj_of(a1), widen(g1));
-                v = madd(v, conj_of(a2), widen(g2));
-                v = madd(v, conj_of(a3), widen(g3));
-            }
-            for (; ip <= k; ip += 4) v = madd(v, conj_of(sc[w][ip]), widen(sG[il][ip]));
-        }
-        const WR part = wave_sum_f64(real_part(mul(c, v)));
-        if (i == 0) snorm[w] = part;
-        __syncthreads();                                        // barrier 2: the four norm parts
-        const WR tot = (snorm[0] + snorm[1]) + (snorm[2] + snorm[3]);
-        const WT e = scale(c, rsqrt(tot > WR(1) ? tot : WR(1)));   // c / sqrt(max(|u_k|^2, 1))
-        if (w == (k & 3) && live) sE[k][i] = e;    // read back only by this same wave (j % 4 == w)
-        if (w == 0 && i < nb) E[(long)k * nb + i] = narrow<T>(e);
-        // next step: spart is rewritten only after every wave has passed barrier 2 (all reads of
-        // it sit between the barriers); snorm is rewritten only after barrier 1 of the next step
+    for (int e = tid; e < nb * nb; e += 256) {          // coalesced read of G; sM[k][i] = G[i][k]
+        const int r = e / nb, cc = e % nb;
+        sM[cc][r] = widen(G[e]);
     }
+    for (int e = tid; e < nb * BMAX; e += 256) {
+        const int k = e / BMAX, ii = e % BMAX;
+        sE[k][ii] = (ii == k) ? from_real<WT>(WR(1)) : zero_of<WT>();
+        if (ii >= nb) sM[k][ii] = zero_of<WT>();
+    }
+    __syncthreads();
+    for (int s0 = 0; s0 < nb; s0 += kAtomSub) {
+        const int s1 = (s0 + kAtomSub < nb) ? s0 + kAtomSub : nb;
+        if (w == 0) {
+            // ---- the dependent steps of this sub-block (one wave, no barriers; ALL 64 lanes run it:
+            //      the DPP reduction reads lane 63) ----
+            const int il = lane_ok ? i : 0;
+            for (int k = s0; k < s1; ++k) {
+                WT c = sE[k][il], y = sM[k][il];
+                WT wv[kAtomSub], ev[kAtomSub], mv[kAtomSub];
+#pragma unroll
+                for (int t = 0; t < kAtomSub; ++t) {      // rows s0 + t < k; loads first, then the sums
+                    const int j = (s0 + t < k) ? s0 + t : s0;
+                    wv[t] = (s0 + t < k) ? widen(sW[k][j]) : zero_of<WT>();
+                    ev[t] = sE[j][il];
+                    mv[t] = sM[j][il];
+                }
+                WT c1 = zero_of<WT>(), y1 = zero_of<WT>();
+#pragma unroll
+                for (int t = 0; t < kAtomSub; t += 2) {
+                    c = msub(c, wv[t], ev[t]);            c1 = msub(c1, wv[t + 1], ev[t + 1]);
+                    y = msub(y, conj_of(wv[t]), mv[t]);   y1 = msub(y1, conj_of(wv[t + 1]), mv[t + 1]);
+                }
+                c = add(c, c1);
+                y = add(y, y1);
+                if (!live || i > k) c = zero_of<WT>();    // support of c_k is i <= k (exact zeros)
+                if (!live) y = zero_of<WT>();
+                const WR tot = wave_sum_f64(real_part(mul(c, y)));
+                const WR rn = rsqrt(tot > WR(1) ? tot : WR(1));      // 1 / sqrt(max(|u_k|^2, 1))
+                const WT e = scale(c, rn);
+                if (lane_ok) {
+                    sE[k][i] = e;
+                    sM[k][i] = scale(y, rn);
+                }
+                if (live) E[(long)k * nb + i] = narrow<T>(e);
+            }
+        }
+        __syncthreads();
+        // ---- every later row loses this sub-block's contribution (rows are independent) ----
+        if (lane_ok) {
+            for (int k = s1 + w; k < nb; k += 4) {
+                WT c = sE[k][i], y = sM[k][i];
+                WT c1 = zero_of<WT>(), y1 = zero_of<WT>();
+#pragma unroll
+                for (int t = 0; t < kAtomSub; t += 2) {
+                    const int j0 = s0 + t, j1 = s0 + t + 1;     // s1 - s0 == kAtomSub here (k >= s1 exists only then)
+                    const WT w0 = widen(sW[k][j0]), w1 = widen(sW[k][j1]);
+                    c = msub(c, w0, sE[j0][i]);            c1 = msub(c1, w1, sE[j1][i]);
+                    y = msub(y, conj_of(w0), sM[j0][i]);   y1 = msub(y1, conj_of(w1), sM[j1][i]);
+                }
+                sE[k][i] = add(c, c1);
+                sM[k][i] = add(y, y1);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <class T>
+constexpr size_t atom_recur_lds_bytes() {
+    return (2 * sizeof(typename wide_of<T>::type) + sizeof(T)) * atom_blk<T>() * atom_blk<T>();
 }
 
 template <class T>
@@ -280,7 +309,17 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
             DCP_LAUNCH_OK(h, hipGetLastError());
         }
         // (3) the b-step recursion in coefficient space
-        hipLaunchKernelGGL((atom_recur_kernel<T>), dim3(1), dim3(256), 0, st, nb, (const T*)w.G,
+        {
+            static DynLdsRaised raised;   // per dtype
+            bool& r = raised.on_current_device();
+            if (!r) {
+                DCP_LAUNCH_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&atom_recur_kernel<T>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)atom_recur_lds_bytes<T>()));
+                r = true;
+            }
+        }
+        hipLaunchKernelGGL((atom_recur_kernel<T>), dim3(1), dim3(256), atom_recur_lds_bytes<T>(), st, nb, (const T*)w.G,
                            (const T*)w.Wl, w.E);
         DCP_LAUNCH_OK(h, hipGetLastError());
         {   // (4) D_new[blk] = E . P

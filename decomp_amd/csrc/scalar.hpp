@@ -64,6 +64,15 @@ template <class R> DCP_HD cx<R> madd(cx<R> acc, cx<R> a, cx<R> b) {
     return acc;
 }
 
+// acc - a*b
+DCP_HD float  msub(float acc, float a, float b)    { return fmaf(-a, b, acc); }
+DCP_HD double msub(double acc, double a, double b) { return fma(-a, b, acc); }
+template <class R> DCP_HD cx<R> msub(cx<R> acc, cx<R> a, cx<R> b) {
+    acc.re -= a.re * b.re - a.im * b.im;
+    acc.im -= a.re * b.im + a.im * b.re;
+    return acc;
+}
+
 DCP_HD float  conj_of(float a)  { return a; }
 DCP_HD double conj_of(double a) { return a; }
 template <class R> DCP_HD cx<R> conj_of(cx<R> a) { return cx<R>{a.re, -a.im}; }
