@@ -54,29 +54,32 @@ DCP_HD c128 cdiv(c128 a, c128 b) {
     return c128{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
 }
 
-// Block preparation: Ablk = rows [k0, k0+nb) of A with the in-block strictly-lower part zeroed;
-// rden_i = 1 / (A_ii + 1e-15); Wl_ij = A_ij * rden_i for j < i (in block), else 0.
+// Preparation of ALL blocks in one launch (blk atoms per block): Ablk = A with every block's
+// in-block strictly-lower part zeroed; rden_r = 1 / (A_rr + 1e-15); Wl[r][j] = A[r][k0 + j] * rden_r for
+// j < r - k0 (k0 = first atom of r's block), else 0.
 template <class T>
-__global__ void __launch_bounds__(256) atom_prep_kernel(int k0, int nb, int K, const T* __restrict__ A,
+__global__ void __launch_bounds__(256) atom_prep_kernel(int blk, int K, const T* __restrict__ A,
                                                         T* __restrict__ Ablk, T* __restrict__ Wl,
                                                         T* __restrict__ rden) {
     typedef typename wide_of<T>::type WT;
     typedef real_t<WT> WR;
-    for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)nb * K; e += (long)gridDim.x * 256L) {
-        const int i = (int)(e / K), j = (int)(e % K);
-        T v = A[(long)(k0 + i) * K + j];
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)K * K; e += (long)gridDim.x * 256L) {
+        const int r = (int)(e / K), j = (int)(e % K);
+        const int k0 = (r / blk) * blk;
+        T v = A[e];
         const int jl = j - k0;
-        if (jl >= 0 && jl < i) v = zero_of<T>();
-        Ablk[(long)i * K + j] = v;
+        if (jl >= 0 && jl < r - k0) v = zero_of<T>();
+        Ablk[e] = v;
     }
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < nb * kAtomBlkMax; e += gridDim.x * 256) {
-        const int i = e / kAtomBlkMax, j = e % kAtomBlkMax;
-        const WT den = add(widen(A[(long)(k0 + i) * K + (k0 + i)]), from_real<WT>(WR(1.0e-15)));
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)K * kAtomBlkMax; e += (long)gridDim.x * 256L) {
+        const int r = (int)(e / kAtomBlkMax), j = (int)(e % kAtomBlkMax);
+        const int k0 = (r / blk) * blk, i = r - k0;
+        const WT den = add(widen(A[(long)r * K + r]), from_real<WT>(WR(1.0e-15)));
         const WT rd = cdiv(from_real<WT>(WR(1)), den);
         T w = zero_of<T>();
-        if (j < i) w = narrow<T>(mul(widen(A[(long)(k0 + i) * K + (k0 + j)]), rd));
-        Wl[i * kAtomBlkMax + j] = w;
-        if (j == 0) rden[i] = narrow<T>(rd);
+        if (j < i) w = narrow<T>(mul(widen(A[(long)r * K + (k0 + j)]), rd));
+        Wl[e] = w;
+        if (j == 0) rden[r] = narrow<T>(rd);
     }
 }
 
@@ -223,12 +226,12 @@ constexpr size_t atom_recur_lds_bytes() {
 
 template <class T>
 struct AtomWs {
-    T* Ablk = nullptr;   // [64, K]
+    T* Ablk = nullptr;   // [K, K]   every block's rows (prepared once per sweep)
     T* P = nullptr;      // [64, F]
     T* G = nullptr;      // [64, 64]
     T* E = nullptr;      // [64, 64]
-    T* Wl = nullptr;     // [64, 64]
-    T* rden = nullptr;   // [64]
+    T* Wl = nullptr;     // [K, 64]
+    T* rden = nullptr;   // [K]
     T* slabs = nullptr;  // split-K partials of G
     size_t slab_count = 0;
     real_t<T>* ext = nullptr;   // complex: real extended images (max(4KF, 4*64*F) reals)
@@ -236,24 +239,24 @@ struct AtomWs {
 
 template <class T>
 inline void atom_plan(WsPlan& p, int64_t F, int64_t K) {
-    p.add<T>((size_t)kAtomBlkMax * K);
+    p.add<T>((size_t)K * K);
     p.add<T>((size_t)kAtomBlkMax * F);
     p.add<T>((size_t)kAtomBlkMax * kAtomBlkMax);
     p.add<T>((size_t)kAtomBlkMax * kAtomBlkMax);
-    p.add<T>((size_t)kAtomBlkMax * kAtomBlkMax);
-    p.add<T>((size_t)kAtomBlkMax);
+    p.add<T>((size_t)K * kAtomBlkMax);
+    p.add<T>((size_t)K);
     p.add<T>((size_t)64 * kAtomBlkMax * kAtomBlkMax);
     if (scalar_traits<T>::is_complex) p.add<real_t<T> >((size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
 }
 
 template <class T>
 inline int atom_carve(dcp_handle* h, AtomWs<T>& w, int64_t F, int64_t K) {
-    w.Ablk = ws_alloc<T>(h, (size_t)kAtomBlkMax * K);
+    w.Ablk = ws_alloc<T>(h, (size_t)K * K);
     w.P = ws_alloc<T>(h, (size_t)kAtomBlkMax * F);
     w.G = ws_alloc<T>(h, (size_t)kAtomBlkMax * kAtomBlkMax);
     w.E = ws_alloc<T>(h, (size_t)kAtomBlkMax * kAtomBlkMax);
-    w.Wl = ws_alloc<T>(h, (size_t)kAtomBlkMax * kAtomBlkMax);
-    w.rden = ws_alloc<T>(h, (size_t)kAtomBlkMax);
+    w.Wl = ws_alloc<T>(h, (size_t)K * kAtomBlkMax);
+    w.rden = ws_alloc<T>(h, (size_t)K);
     w.slab_count = (size_t)64 * kAtomBlkMax * kAtomBlkMax;
     w.slabs = ws_alloc<T>(h, w.slab_count);
     if (scalar_traits<T>::is_complex) {
@@ -282,26 +285,39 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
     hipStream_t st = h->stream;
     const int K = (int)K64, F = (int)F64;
     constexpr int BLK = atom_blk<T>();
+    hipLaunchKernelGGL((atom_prep_kernel<T>), dim3(grid_for((long)K * K, 256)), dim3(256), 0, st, BLK, K, A,
+                       w.Ablk, w.Wl, w.rden);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    {
+        static DynLdsRaised raised;   // per dtype
+        bool& r = raised.on_current_device();
+        if (!r) {
+            DCP_LAUNCH_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&atom_recur_kernel<T>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)atom_recur_lds_bytes<T>()));
+            r = true;
+        }
+    }
+    // The 64-row products of a block run on few CUs and are latency bound: 64-deep K blocks
+    // (TILE_SMALL_DEEP) put 4x more loads in flight per barrier than the 16-deep small tile.
     for (int k0 = 0; k0 < K; k0 += BLK) {
         const int nb = (K - k0) < BLK ? (K - k0) : BLK;
-        hipLaunchKernelGGL((atom_prep_kernel<T>), dim3(grid_for((long)nb * K, 64)), dim3(256), 0, st, k0,
-                           nb, K, A, w.Ablk, w.Wl, w.rden);
-        DCP_LAUNCH_OK(h, hipGetLastError());
+        const T* rden = w.rden + k0;
         {   // (1) P = (B_blk - Ablk . D_cur) * rden + D_old[blk]
             GemmArgs<T> a;
-            a.A = w.Ablk; a.lda = K; a.B = Dnew; a.ldb = F; a.M = nb; a.N = F; a.K = K;
-            a.tile = TILE_SMALL;
+            a.A = w.Ablk + (long)k0 * K; a.lda = K; a.B = Dnew; a.ldb = F; a.M = nb; a.N = F; a.K = K;
+            a.tile = TILE_SMALL_DEEP;
             a.ext_ws = w.ext;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiAtomP<T>{B + (long)k0 * F, Dnew + (long)k0 * F,
-                                                              w.rden, w.P, (long)F})));
+                                                              rden, w.P, (long)F})));
         }
-        {   // (2) G = P P^H
+        {   // (2) G = P P^H : one 64-deep K block per split
             GemmArgs<T> g;
             g.A = w.P; g.lda = F; g.B = w.P; g.ldb = F; g.M = nb; g.N = nb; g.K = F;
             g.conjB = true;
-            g.tile = TILE_SMALL;
+            g.tile = TILE_SMALL_DEEP;
             g.ext_ws = w.ext;
-            plan_splits<FORM_NT>(g, 64, 64);
+            plan_splits<FORM_NT>(g, 64, 64, 4);
             if ((size_t)g.ksplits * nb * nb > w.slab_count) return fail(h, DCP_ERR_INTERNAL, "atom slab plan");
             DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, g, EpiSlab<T>{w.slabs, (long)nb, (long)nb * nb})));
             hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)nb * nb, 16)), dim3(256), 0, st,
@@ -309,23 +325,13 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
             DCP_LAUNCH_OK(h, hipGetLastError());
         }
         // (3) the b-step recursion in coefficient space
-        {
-            static DynLdsRaised raised;   // per dtype
-            bool& r = raised.on_current_device();
-            if (!r) {
-                DCP_LAUNCH_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&atom_recur_kernel<T>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)atom_recur_lds_bytes<T>()));
-                r = true;
-            }
-        }
-        hipLaunchKernelGGL((atom_recur_kernel<T>), dim3(1), dim3(256), atom_recur_lds_bytes<T>(), st, nb, (const T*)w.G,
-                           (const T*)w.Wl, w.E);
+        hipLaunchKernelGGL((atom_recur_kernel<T>), dim3(1), dim3(256), atom_recur_lds_bytes<T>(), st, nb,
+                           (const T*)w.G, (const T*)(w.Wl + (long)k0 * kAtomBlkMax), w.E);
         DCP_LAUNCH_OK(h, hipGetLastError());
         {   // (4) D_new[blk] = E . P
             GemmArgs<T> a;
             a.A = w.E; a.lda = nb; a.B = w.P; a.ldb = F; a.M = nb; a.N = F; a.K = nb;
-            a.tile = TILE_SMALL;
+            a.tile = TILE_SMALL_DEEP;
             a.ext_ws = w.ext;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiStore<T>{Dnew + (long)k0 * F, (long)F})));
         }

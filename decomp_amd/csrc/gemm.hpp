@@ -17,7 +17,7 @@ namespace dcp {
 //   NT: C[M,N] = A[M,K] . B[N,K]^T(H)      NN: C[M,N] = A[M,K] . B[K,N]
 //   TN: C[M,N] = A[K,M]^T(H) . B[K,N]
 enum GemmForm { FORM_NT = 0, FORM_NN = 1, FORM_TN = 2 };
-enum TileSel { TILE_AUTO = 0, TILE_LARGE = 1, TILE_SMALL = 2, TILE_HUGE = 3 };
+enum TileSel { TILE_AUTO = 0, TILE_LARGE = 1, TILE_SMALL = 2, TILE_HUGE = 3, TILE_SMALL_DEEP = 4 };
 
 template <class T>
 struct GemmArgs {
@@ -98,8 +98,10 @@ typedef TileCfg<128, 128, 16, 64, 32, 2> CfgMid;       // 8 waves: mid-size outp
                                                       // y.A^H / v.AAt of an 8192-row minibatch: +8 % over 64x64
 typedef TileCfg<64, 64, 16, 32, 32, 2> CfgSmall;
 typedef TileCfg<32, 128, 32, 32, 32, 2> CfgFlat;       // <= 32 output rows (atom-block residuals)
+typedef TileCfg<64, 64, 64, 32, 32, 1> CfgSmallDeep;   // 64 KiB LDS: latency-bound products on few CUs (64-row
+                                                      // atom-block GEMMs): 4x fewer, 4x larger K blocks in flight
 
-enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2, TIER_FLAT = 3, TIER_MID = 4 };
+enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2, TIER_FLAT = 3, TIER_MID = 4, TIER_SMALL_DEEP = 5 };
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
@@ -116,6 +118,7 @@ inline void tier_dims(int tier, int& bm, int& bn) {
 template <int FORM>
 inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
     if (tile_sel == TILE_SMALL) return TIER_SMALL;
+    if (tile_sel == TILE_SMALL_DEEP) return TIER_SMALL_DEEP;
     if (tile_sel == TILE_LARGE) return TIER_LARGE;
     if (tile_sel == TILE_HUGE) return FORM == FORM_TN ? TIER_LARGE : TIER_HUGE;
     long splits = will_split ? K / 512 : 1;
@@ -138,7 +141,7 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
 // float64 products big enough for the 128 x 128 fp64 MFMA tile; smaller ones stay on the
 // generic 64 x 64 core (more workgroups for thin outputs).
 inline bool f64_on_mfma(int M, int N, int tile_sel) {
-    if (tile_sel == TILE_SMALL) return false;
+    if (tile_sel == TILE_SMALL || tile_sel == TILE_SMALL_DEEP) return false;
     return M >= 128 && N >= 128;
 }
 
@@ -197,6 +200,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
         const int tier = pick_tier<FORM>(a.M, a.N, a.K, a.tile, a.split_planned);
         if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL, Epi>(stream, p, epi);
+        if (tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmallDeep, AL, BL, Epi>(stream, p, epi);
         if constexpr (FORM != FORM_TN) {
             if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL, Epi>(stream, p, epi);
             if (tier == TIER_MID) return launch_gemm_mfma<CfgMid, AL, BL, Epi>(stream, p, epi);
@@ -223,7 +227,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     p.M = 2 * a.M; p.N = 2 * a.N; p.K = a.K;
                     CplxTnEpi<Epi> ce{epi};
                     const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
-                    if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
+                    if (tier == TIER_SMALL || tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
                 } else {
                     // ext(B): [2 rows(B), 2 cols(B)] real image in the caller's scratch
@@ -239,7 +243,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     if (a.ksplits <= 1) p.klen = 0;
                     CplxColEpi<Epi> ce{epi};
                     const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
-                    if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
+                    if (tier == TIER_SMALL || tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
                     if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL>(stream, p, ce);
                     if (tier == TIER_MID) return launch_gemm_mfma<CfgMid, AL, BL>(stream, p, ce);
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
