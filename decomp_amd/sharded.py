@@ -171,6 +171,7 @@ class HipDictBackend(object):
         self.stats = torch.empty((self.K, self.F + self.K), dtype=D.dtype, device=D.device)
         rdt = torch.float32 if D.dtype in (torch.float32, torch.complex64) else torch.float64
         self.md = torch.zeros((1,), dtype=rdt, device=D.device)
+        self._host_md = None
         self.lasso_it = ctypes.c_int(0)
 
     def local_stats(self, y_rows, x_rows, D):
@@ -190,62 +191,134 @@ class HipDictBackend(object):
                          _arrays.ptr(D_new), self.F, self.K, _arrays.ptr(self.md)), 'dcp_dict_update')
         return float(self.md.item())
 
-    def zeros_like_rows(self, x_mb):
-        return self.torch.zeros_like(x_mb)
+    def update_async(self, stats, beta, A, B, D, D_new):
+        """Enqueue the A/B accumulation + atom sweep; max|D - D_new| stays on the device."""
+        lib, h = _arrays.lib_handle(D)
+        fn = getattr(lib, 'dcp_dict_update_' + self.sfx)
+        _hip.check(h, fn(h, _arrays.ptr(stats), float(beta), _arrays.ptr(A), _arrays.ptr(B), _arrays.ptr(D),
+                         _arrays.ptr(D_new), self.F, self.K, _arrays.ptr(self.md)), 'dcp_dict_update')
+
+    def maxdiff_token(self, slot):
+        """Start the copy of the device max|dD| into pinned host slot ``slot`` (0 / 1) and return a
+        token for ``read_maxdiff`` -- read one step later, when the next step is already enqueued."""
+        if self._host_md is None:
+            self._host_md = self.torch.zeros((2,), dtype=self.md.dtype).pin_memory()
+        self._host_md[slot:slot + 1].copy_(self.md, non_blocking=True)
+        ev = self.torch.cuda.Event()
+        ev.record()
+        return (ev, slot)
+
+    def read_maxdiff(self, token):
+        ev, slot = token
+        ev.synchronize()
+        return float(self._host_md[slot])
+
+    def gather(self, src, index_dev, n, out):
+        """out[:n] = src[index[:n]] (rows; HIP row mover)."""
+        if n:
+            from .utils import data as _data
+            _data._move_rows('dcp_gather_rows_bytes', src, index_dev, n, src.shape[1] * src.element_size(), out)
+
+    def scatter(self, src, index_dev, n, out):
+        """out[index[:n]] = src[:n]."""
+        if n:
+            from .utils import data as _data
+            _data._move_rows('dcp_scatter_rows_bytes', src, index_dev, n, src.shape[1] * src.element_size(), out)
 
 
-def dict_loop(backend, ybat, xbat, D, tol, minibatch, maxiter, rng, new_like, zeros, group=None,
-              world_size=1, rank=0):
-    """dictionary_learning.py:114-168 with every minibatch's rows split over the ranks.
+def dict_loop(backend, y_local, x_local, row0, n_total, D, tol, minibatch, maxiter, rng, new_like, zeros,
+              index_to_device, group=None, world_size=1):
+    """dictionary_learning.py:114-168 with the SAMPLES sharded: rank r owns the original rows
+    [row0, row0 + len(y_local)) of y and x for the whole run -- nothing but the [K, F+K] statistics
+    ever crosses ranks, ONE all-reduce per minibatch step (north_star).
 
-    Every rank holds the full (identically shuffled) y and x containers and the same D; rank r
-    runs the LASSO and the x^H [y | x] product on its contiguous share of each minibatch, the
-    [K, F+K] statistics are summed with ONE all-reduce, the A/B update and the sequential atom
-    sweep run redundantly (identical input -> identical D_new and stop decision), and the
-    minibatch's updated codes are re-assembled with a second all-reduce (each rank contributes
-    its rows, zeros elsewhere: exact).  Returns (it, D, x in the original row order)."""
+    Every rank draws the same permutation stream from the shared ``RandomState`` (the reference's
+    cumulative shuffle, data.py:152-156), so minibatch m of an epoch is the same SET of original rows
+    as in the single-process run; each rank processes the members of that set it owns (its share
+    varies around minibatch / world_size), gathers them into a staging block, runs the LASSO and
+    x^H [y | x] on it (``dcp_dict_stats_*``), scatters the new codes back into its own x, and the
+    summed statistics drive the identical, redundant A/B update + atom sweep on every rank.
+    max|D - D_new| is read one step late (as the NMF loop does): the next minibatch is already
+    enqueued when the host looks at it, and is discarded if the test had passed.
+
+    Deviations from the single-process run, both at rounding / tolerance level: the statistics are
+    summed in a different order; the LASSO's early exit (|dx| < lasso_tol on iterations 0, 10, ...,
+    lasso.py:293) is taken per rank on its own rows instead of on the whole minibatch.
+    Returns (it, D, x_local)."""
     import torch.distributed as dist
     import numpy as np
+    import torch
     K, F = D.shape
     A = zeros((K, K))
     B = zeros((K, F))
     D_new = new_like(D)
-    index = np.arange(ybat.size)
-    bounds = np.linspace(0, minibatch, world_size + 1).astype(np.int64)
-    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    n_local = y_local.shape[0]
+    cap = min(n_local, minibatch)
+    y_stage = torch.empty((max(cap, 1), F), dtype=y_local.dtype, device=y_local.device)
+    x_stage = torch.empty((max(cap, 1), K), dtype=x_local.dtype, device=x_local.device)
+    order = np.arange(n_total)                  # position -> original row, composed over epochs
+    index = np.arange(n_total)
+    n_loop = int(n_total / minibatch)
+    if n_total < minibatch:
+        raise ValueError('Minibatch size should be smaller than the total '
+                         'size. Given {} < {}'.format(n_total, minibatch))
     count = 0
+    pending = None                              # (max|dD| token, it, D_new) of the step before
+    step = 0
     for it in range(1, maxiter):
-        rng.shuffle(index)
-        ybat.shuffle(index)
-        xbat.shuffle(index)
-        for y_mb, x_mb in zip(ybat, xbat):
-            stats = backend.local_stats(y_mb[lo:hi], x_mb[lo:hi], D)
+        rng.shuffle(index)                      # dictionary_learning.py:131-133
+        order = order[index]
+        for m in range(n_loop):
+            rows = order[m * minibatch:(m + 1) * minibatch]
+            mine = rows[(rows >= row0) & (rows < row0 + n_local)] - row0
+            n = int(mine.shape[0])
+            idx = index_to_device(mine) if n else None
+            backend.gather(y_local, idx, n, y_stage)
+            backend.gather(x_local, idx, n, x_stage)
+            if n:
+                stats = backend.local_stats(y_stage[:n], x_stage[:n], D)
+            else:                               # this rank owns no row of the minibatch
+                stats = backend.stats.zero_()
             if world_size > 1:
-                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-                gathered = backend.zeros_like_rows(x_mb)
-                gathered[lo:hi] = x_mb[lo:hi]
-                dist.all_reduce(gathered, op=dist.ReduceOp.SUM, group=group)
-                x_mb[...] = gathered
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)     # the ONLY collective
             theta_plus1 = count * minibatch + 1.0
             beta = (theta_plus1 - minibatch) / theta_plus1
-            if backend.update(stats, beta, A, B, D, D_new) < tol:
-                return it, D_new, xbat.array
-            D, D_new = D_new, D
+            backend.update_async(stats, beta, A, B, D, D_new)
+            token = backend.maxdiff_token(step & 1)
+            # stop test of the PREVIOUS step, now that this one is enqueued
+            if pending is not None:
+                ptoken, pit, pD = pending
+                if backend.read_maxdiff(ptoken) < tol:  # dictionary_learning.py:161-162
+                    # step `step` ran speculatively on the converged dictionary: its codes are
+                    # not scattered, A / B / D_new of it are dropped
+                    return pit, pD, x_local
+            backend.scatter(x_stage, idx, n, x_local)
+            pending = (token, it, D_new)
+            D, D_new = D_new, D                 # the old D is the scratch of the next step
             count += 1
-    return maxiter, D, xbat.array
+            step += 1
+    if pending is not None:
+        ptoken, pit, pD = pending
+        if backend.read_maxdiff(ptoken) < tol:
+            return pit, pD, x_local
+    return maxiter, D, x_local
 
 
-def dictionary_learning_sharded(y, D, alpha, x=None, tol=1.0e-3, minibatch=None, maxiter=1000,
+def dictionary_learning_sharded(y_local, D, alpha, x_local=None, tol=1.0e-3, minibatch=None, maxiter=1000,
                                 lasso_method='cd', lasso_iter=10, lasso_tol=1.0e-5, random_seed=None,
                                 group=None):
-    """``decomp.dictionary_learning.solve(method='block_cd')`` with the work of every minibatch
-    split over the ranks of ``group``.  Every rank passes the same full y / D / x (torch CUDA
-    tensors or NumPy) and the same ``random_seed``; all ranks return the same (it, D, x)."""
+    """``decomp.dictionary_learning.solve(method='block_cd')`` for a sample-sharded problem.
+
+    Every rank passes ITS rows of y (and of x), the same D, alpha, ``minibatch`` (the GLOBAL
+    minibatch size) and ``random_seed``; ranks hold consecutive row ranges in rank order (sizes may
+    differ).  Returns (it, D, x_local): it and D identical on all ranks, x_local this rank's codes
+    in its original row order.  torch.distributed must be initialised (backend "nccl" = RCCL on
+    ROCm) unless the world size is 1; one tiny all-gather of the row counts at set-up, then exactly
+    one all-reduce of the [K, F+K] statistics per minibatch step."""
     import numpy as np
     import torch
     import torch.distributed as dist
     from . import lasso
-    from .utils.data import MinibatchData
     if minibatch is None:
         raise NotImplementedError('Only online methods are implemented. minibatch is required.')
     lasso._dict_method_code(lasso_method)      # NotImplementedError for unknown solvers
@@ -253,17 +326,27 @@ def dictionary_learning_sharded(y, D, alpha, x=None, tol=1.0e-3, minibatch=None,
     world = dist.get_world_size(group) if init else 1
     rank = dist.get_rank(group) if init else 0
     kind = _arrays.get_array_module(D)
-    yd = _arrays.to_device(y)
+    yd = _arrays.to_device(y_local)
     Dd = _arrays.to_device(D, copy=True)
-    if x is None:
-        xd = torch.ones((yd.shape[0], Dd.shape[0]), dtype=Dd.dtype, device=Dd.device)
+    if x_local is None:
+        xd = torch.ones((yd.shape[0], Dd.shape[0]), dtype=Dd.dtype, device=Dd.device)   # :58-59
     else:
-        xd = _arrays.to_device(x, copy=True)
+        xd = _arrays.to_device(x_local, copy=True)
+    counts = [int(yd.shape[0])]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, int(yd.shape[0]), group=group)
+        counts = [int(c) for c in gathered]
+    row0 = int(sum(counts[:rank]))
+    n_total = int(sum(counts))
     _arrays.l2_normalize_(Dd, strict=True)
     backend = HipDictBackend(Dd, lasso_method, lasso_iter, lasso_tol, alpha)
     rng = np.random.RandomState(random_seed)
+
+    def index_to_device(idx):
+        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(Dd.device)
     it, Dout, xout = dict_loop(
-        backend, MinibatchData(yd, minibatch), MinibatchData(xd, minibatch), Dd, tol, minibatch, maxiter,
-        rng, torch.empty_like, lambda shape: torch.zeros(shape, dtype=Dd.dtype, device=Dd.device),
-        group=group, world_size=world, rank=rank)
+        backend, yd, xd, row0, n_total, Dd, tol, minibatch, maxiter, rng, torch.empty_like,
+        lambda shape: torch.zeros(shape, dtype=Dd.dtype, device=Dd.device), index_to_device,
+        group=group, world_size=world)
     return it, _arrays.to_caller(Dout, kind), _arrays.to_caller(xout, kind)

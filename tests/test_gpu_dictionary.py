@@ -306,15 +306,24 @@ def _dl_gloo_gpu_worker(rank, world, port, q):
     try:
         from decomp_amd import sharded
         y, D0 = _sharded_dl_problem()
-        it, D, x = sharded.dictionary_learning_sharded(y.copy(), D0.copy(), 0.02, **_DL_KW)
-        q.put((rank, it, D, x))
+        lo, hi = (0, 100) if rank == 0 else (100, y.shape[0])      # unequal shards, owned for the whole run
+        calls = {'n': 0}
+        real = dist.all_reduce
+
+        def counting(*a, **k):
+            calls['n'] += 1
+            return real(*a, **k)
+        dist.all_reduce = counting
+        it, D, x = sharded.dictionary_learning_sharded(y[lo:hi].copy(), D0.copy(), 0.02, **_DL_KW)
+        q.put((rank, it, D, x, calls['n']))
     finally:
         dist.destroy_process_group()
 
 
 def test_sharded_dictionary_two_ranks_on_one_gpu_gloo():
-    """Minibatch rows split over two processes sharing the test box's GPU; statistics and codes
-    exchanged over gloo: must reproduce the single-process result to rounding."""
+    """Samples sharded over two processes sharing the test box's GPU (each owns its rows of y and x for
+    the whole run); ONLY the [K, F+K] statistics cross ranks, one all-reduce per minibatch step over
+    gloo: must reproduce the single-process result to rounding."""
     import os
     import torch.multiprocessing as mp
     from decomp_amd import dictionary_learning as dl
@@ -331,5 +340,9 @@ def test_sharded_dictionary_two_ranks_on_one_gpu_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] == res[1][1] == it1
-    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
-    assert _err(res[0][2], D1) < 1e-4 and _err(res[0][3], x1) < 1e-3
+    assert np.array_equal(res[0][2], res[1][2])                       # replicated D: bit-identical
+    x_all = np.concatenate([res[0][3], res[1][3]], axis=0)            # rank order = original row order
+    assert res[0][3].shape[0] == 100 and x_all.shape == x1.shape
+    assert _err(res[0][2], D1) < 1e-4 and _err(x_all, x1) < 1e-3
+    n_steps = (_DL_KW['maxiter'] - 1) * (y.shape[0] // _DL_KW['minibatch'])
+    assert res[0][4] == res[1][4] == n_steps                          # exactly one collective per step

@@ -114,19 +114,21 @@ def test_two_rank_sharded_loop_equals_single_process(lik, masked):
 class OracleDictBackend(object):
     """Same interface as decomp_amd.sharded.HipDictBackend, arithmetic by the oracle."""
 
-    def __init__(self, lasso_method, lasso_iter, lasso_tol, alpha):
+    def __init__(self, lasso_method, lasso_iter, lasso_tol, alpha, K, F):
         self.lm, self.li, self.lt, self.alpha = lasso_method, lasso_iter, lasso_tol, alpha
+        self.stats = torch.zeros((K, F + K), dtype=torch.float64)
+        self._md = 0.0
 
     def local_stats(self, y_rows, x_rows, D):
         from oracle import lasso as olasso
         yn, xn, Dn = y_rows.numpy(), x_rows.numpy(), D.numpy()
-        if len(yn):
-            _, xs = olasso.solve_fastpath(yn, Dn, self.alpha, xn, self.lt, self.li, self.lm)
-            xn[...] = xs
+        _, xs = olasso.solve_fastpath(yn, Dn, self.alpha, xn, self.lt, self.li, self.lm)
+        xn[...] = xs
         xH = np.conj(xn.T)
-        return torch.from_numpy(np.ascontiguousarray(np.concatenate([xH @ yn, xH @ xn], axis=1)))
+        self.stats.copy_(torch.from_numpy(np.ascontiguousarray(np.concatenate([xH @ yn, xH @ xn], axis=1))))
+        return self.stats
 
-    def update(self, stats, beta, A, B, D, D_new):
+    def update_async(self, stats, beta, A, B, D, D_new):
         from oracle.dictionary_learning import atom_sweep
         s = stats.numpy()
         F = D.shape[1]
@@ -134,34 +136,21 @@ class OracleDictBackend(object):
         B[...] = torch.from_numpy(beta * B.numpy() + s[:, :F])
         out = atom_sweep(D.numpy(), A.numpy(), B.numpy())
         D_new.copy_(torch.from_numpy(out))
-        return float(np.max(np.abs(D.numpy() - out)))
+        self._md = float(np.max(np.abs(D.numpy() - out)))
 
-    def zeros_like_rows(self, x_mb):
-        return torch.zeros_like(x_mb)
+    def maxdiff_token(self, slot):
+        return self._md
 
+    def read_maxdiff(self, token):
+        return token
 
-class _CpuBatches(object):
-    """decomp_amd.utils.data.MinibatchData semantics on CPU torch tensors (test stand-in)."""
+    def gather(self, src, index, n, out):
+        if n:
+            out[:n] = src[index]
 
-    def __init__(self, t, mb):
-        self._a, self.minibatch, self.size = t, mb, t.shape[0]
-        self.restore = np.arange(self.size)
-
-    @property
-    def n_loop(self):
-        return int(self.size / self.minibatch)
-
-    def shuffle(self, idx):
-        self._a = self._a[torch.from_numpy(idx)]
-        self.restore = self.restore[idx]
-
-    @property
-    def array(self):
-        return self._a[torch.from_numpy(self.restore.argsort())]
-
-    def __iter__(self):
-        for r in range(self.n_loop):
-            yield self._a[r * self.minibatch:(r + 1) * self.minibatch]
+    def scatter(self, src, index, n, out):
+        if n:
+            out[index] = src[:n]
 
 
 def _dl_problem():
@@ -172,7 +161,7 @@ def _dl_problem():
     return y, Dt + 0.2 * rng.randn(3, 5)
 
 
-def _dl_worker(rank, world, port, q):
+def _dl_worker(rank, world, port, q, tol):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -181,27 +170,41 @@ def _dl_worker(rank, world, port, q):
         from decomp_amd import sharded
         from oracle.common import l2_strict
         y, D0 = _dl_problem()
-        be = OracleDictBackend('ista', 8, 1e-5, 0.1)
+        N = y.shape[0]
+        bounds = [0, 40, N]                       # unequal shards: 40 and 63 rows
+        lo, hi = bounds[rank], bounds[rank + 1]
+        be = OracleDictBackend('ista', 8, 1e-5, 0.1, 3, 5)
         D = torch.from_numpy(l2_strict(D0))
         rng = np.random.RandomState(4)
+        calls = {'n': 0}
+        real_all_reduce = dist.all_reduce
+
+        def counting_all_reduce(*a, **k):
+            calls['n'] += 1
+            return real_all_reduce(*a, **k)
+        dist.all_reduce = counting_all_reduce
         it, Dout, xout = sharded.dict_loop(
-            be, _CpuBatches(torch.from_numpy(y.copy()), 25), _CpuBatches(torch.ones((103, 3), dtype=torch.float64), 25),
-            D, 0.0, 25, 4, rng, torch.empty_like, lambda shape: torch.zeros(shape, dtype=torch.float64),
-            world_size=world, rank=rank)
-        q.put((rank, it, Dout.numpy().copy(), xout.numpy().copy()))
+            be, torch.from_numpy(y[lo:hi].copy()), torch.ones((hi - lo, 3), dtype=torch.float64), lo, N,
+            D, tol, 25, 4, rng, torch.empty_like, lambda shape: torch.zeros(shape, dtype=torch.float64),
+            lambda idx: torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)), world_size=world)
+        q.put((rank, it, Dout.numpy().copy(), xout.numpy().copy(), calls['n']))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_sharded_dictionary_learning_equals_single_process():
+@pytest.mark.parametrize('tol', [0.0, 0.05])
+def test_two_rank_sharded_dictionary_learning_equals_single_process(tol):
+    """Rows owned by the ranks for the whole run (40 + 63 of 103), the global minibatch composition of
+    the shared RandomState, ONE all-reduce per minibatch step and nothing else; with tol > 0 the lagged
+    stop test must return exactly the reference's iteration, dictionary and codes."""
     from oracle import dictionary_learning as odl
     y, D0 = _dl_problem()
-    it_ref, D_ref, x_ref = odl.solve(y.copy(), D0.copy(), 0.1, tol=0.0, minibatch=25, maxiter=4,
+    it_ref, D_ref, x_ref = odl.solve(y.copy(), D0.copy(), 0.1, tol=tol, minibatch=25, maxiter=4,
                                      lasso_method='ista', lasso_iter=8, lasso_tol=1e-5, random_seed=4)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 1500)
-    procs = [ctx.Process(target=_dl_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dl_worker, args=(r, 2, port, q, tol)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
@@ -209,6 +212,16 @@ def test_two_rank_sharded_dictionary_learning_equals_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] == res[1][1] == it_ref
-    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    if tol > 0:
+        assert it_ref < 4                        # the stop test really fired
+    assert np.array_equal(res[0][2], res[1][2])                  # replicated D is bit-identical
     assert np.allclose(res[0][2], D_ref, rtol=1e-9, atol=1e-12)
-    assert np.allclose(res[0][3], x_ref, rtol=1e-9, atol=1e-12)
+    x_all = np.concatenate([res[0][3], res[1][3]], axis=0)       # rank order = original row order
+    assert np.allclose(x_all, x_ref, rtol=1e-9, atol=1e-12)
+    # exactly one collective per executed minibatch step (the speculative step after a passed stop
+    # test included), the same number on both ranks
+    assert res[0][4] == res[1][4]
+    n_loop = 103 // 25
+    assert res[0][4] <= (4 - 1) * n_loop and res[0][4] >= 1
+    if tol == 0.0:
+        assert res[0][4] == (4 - 1) * n_loop
