@@ -128,11 +128,10 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 // and |u_k|^2 = c_k G c_k^H = Re sum_i c_k[i] y_k[i] is ONE wave reduction; then
 //     E_k = c_k / n ,  M_k = y_k / n ,  n = sqrt(max(|u_k|^2, 1))     (M_k comes for free).
 // Right-looking in sub-blocks of 8 atoms: rows k of the two LDS images start as (e_k, G[:, k]) and
-// carry the partial sums; wave 0 runs the 8 dependent steps of a sub-block (at most 7 terms each,
-// same-wave LDS traffic is ordered: no barrier inside), then ALL four waves subtract that sub-block's
-// contribution from every later row (independent rows: 8 terms each).  The sequential chain of a step
-// is thus ~8 terms + one DPP reduction + one rsqrt instead of k terms; two barriers per 8 atoms instead
-// of two per atom.  G (b x b, leading dim nb), Wl (leading dim kAtomBlkMax) -> E (leading dim nb).
+// carry the partial sums; wave 0 runs the 8 dependent steps of a sub-block entirely in registers, then
+// ALL four waves subtract that sub-block's contribution from every later row (independent rows: 8 terms
+// each).  The sequential chain of a step is two FMAs, one DPP reduction and one rsqrt instead of k
+// LDS-fed terms; two barriers per 8 atoms instead of two per atom.  G (b x b, leading dim nb), Wl (leading dim kAtomBlkMax) -> E (leading dim nb).
 constexpr int kAtomSub = 8;
 
 template <class T>
@@ -165,37 +164,44 @@ __global__ void __launch_bounds__(256) atom_recur_kernel(int nb, const T* __rest
     for (int s0 = 0; s0 < nb; s0 += kAtomSub) {
         const int s1 = (s0 + kAtomSub < nb) ? s0 + kAtomSub : nb;
         if (w == 0) {
-            // ---- the dependent steps of this sub-block (one wave, no barriers; ALL 64 lanes run it:
-            //      the DPP reduction reads lane 63) ----
+            // ---- the dependent steps of this sub-block: one wave, registers only (ALL 64 lanes run
+            //      it: the DPP reduction reads lane 63).  The sub-block's pending rows and its w_kj are
+            //      fetched up front; a finished row is applied to the later rows of the sub-block right
+            //      away (right-looking), so the dependent chain of a step is
+            //      2 FMAs -> product -> DPP reduction -> rsqrt -> 2 scalings: no LDS round trip. ----
             const int il = lane_ok ? i : 0;
-            for (int k = s0; k < s1; ++k) {
-                WT c = sE[k][il], y = sM[k][il];
-                WT wv[kAtomSub], ev[kAtomSub], mv[kAtomSub];
+            const int cnt = s1 - s0;
+            WT cp[kAtomSub], yp[kAtomSub], wv[kAtomSub][kAtomSub];
 #pragma unroll
-                for (int t = 0; t < kAtomSub; ++t) {      // rows s0 + t < k; loads first, then the sums
-                    const int j = (s0 + t < k) ? s0 + t : s0;
-                    wv[t] = (s0 + t < k) ? widen(sW[k][j]) : zero_of<WT>();
-                    ev[t] = sE[j][il];
-                    mv[t] = sM[j][il];
-                }
-                WT c1 = zero_of<WT>(), y1 = zero_of<WT>();
+            for (int t = 0; t < kAtomSub; ++t) {
+                const int k = (t < cnt) ? s0 + t : s0;
+                cp[t] = sE[k][il];
+                yp[t] = sM[k][il];
 #pragma unroll
-                for (int t = 0; t < kAtomSub; t += 2) {
-                    c = msub(c, wv[t], ev[t]);            c1 = msub(c1, wv[t + 1], ev[t + 1]);
-                    y = msub(y, conj_of(wv[t]), mv[t]);   y1 = msub(y1, conj_of(wv[t + 1]), mv[t + 1]);
+                for (int j = 0; j < t; ++j) wv[t][j] = (t < cnt) ? widen(sW[k][s0 + j]) : zero_of<WT>();
+            }
+#pragma unroll
+            for (int t = 0; t < kAtomSub; ++t) {
+                if (t < cnt) {                                   // wave-uniform
+                    const int k = s0 + t;
+                    WT c = cp[t], y = yp[t];
+                    if (!live || i > k) c = zero_of<WT>();        // support of c_k is i <= k (exact zeros)
+                    if (!live) y = zero_of<WT>();
+                    const WR tot = wave_sum_f64(real_part(mul(c, y)));
+                    const WR rn = rsqrt(tot > WR(1) ? tot : WR(1));      // 1 / sqrt(max(|u_k|^2, 1))
+                    const WT e = scale(c, rn);
+                    const WT m = scale(y, rn);
+#pragma unroll
+                    for (int t2 = t + 1; t2 < kAtomSub; ++t2) {   // later rows of the sub-block
+                        cp[t2] = msub(cp[t2], wv[t2][t], e);
+                        yp[t2] = msub(yp[t2], conj_of(wv[t2][t]), m);
+                    }
+                    if (lane_ok) {
+                        sE[k][i] = e;
+                        sM[k][i] = m;
+                    }
+                    if (live) E[(long)k * nb + i] = narrow<T>(e);
                 }
-                c = add(c, c1);
-                y = add(y, y1);
-                if (!live || i > k) c = zero_of<WT>();    // support of c_k is i <= k (exact zeros)
-                if (!live) y = zero_of<WT>();
-                const WR tot = wave_sum_f64(real_part(mul(c, y)));
-                const WR rn = rsqrt(tot > WR(1) ? tot : WR(1));      // 1 / sqrt(max(|u_k|^2, 1))
-                const WT e = scale(c, rn);
-                if (lane_ok) {
-                    sE[k][i] = e;
-                    sM[k][i] = scale(y, rn);
-                }
-                if (live) E[(long)k * nb + i] = narrow<T>(e);
             }
         }
         __syncthreads();
