@@ -57,10 +57,14 @@ DCP_HD c128 cdiv(c128 a, c128 b) {
 // Preparation of ALL blocks in one launch (blk atoms per block): Ablk = A with every block's
 // in-block strictly-lower part zeroed; rden_r = 1 / (A_rr + 1e-15); Wl[r][j] = A[r][k0 + j] * rden_r for
 // j < r - k0 (k0 = first atom of r's block), else 0.
+// Look-ahead images: Alook = Ablk with the PREVIOUS block's columns zeroed as well (the part of P that
+// does not wait for that block), Aprev[r][j] = -rden_r * A[r][k0 - blk + j] (its contribution, applied
+// once the previous block's atoms exist).
 template <class T>
 __global__ void __launch_bounds__(256) atom_prep_kernel(int blk, int K, const T* __restrict__ A,
                                                         T* __restrict__ Ablk, T* __restrict__ Wl,
-                                                        T* __restrict__ rden) {
+                                                        T* __restrict__ rden, T* __restrict__ Alook,
+                                                        T* __restrict__ Aprev) {
     typedef typename wide_of<T>::type WT;
     typedef real_t<WT> WR;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)K * K; e += (long)gridDim.x * 256L) {
@@ -70,6 +74,19 @@ __global__ void __launch_bounds__(256) atom_prep_kernel(int blk, int K, const T*
         const int jl = j - k0;
         if (jl >= 0 && jl < r - k0) v = zero_of<T>();
         Ablk[e] = v;
+        if (jl < 0 && jl >= -blk) v = zero_of<T>();
+        Alook[e] = v;
+    }
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)K * kAtomBlkMax; e += (long)gridDim.x * 256L) {
+        const int r = (int)(e / kAtomBlkMax), j = (int)(e % kAtomBlkMax);
+        const int k0 = (r / blk) * blk;
+        T v = zero_of<T>();
+        if (k0 >= blk && j < blk) {
+            const WT den = add(widen(A[(long)r * K + r]), from_real<WT>(WR(1.0e-15)));
+            const WT rd = cdiv(from_real<WT>(WR(1)), den);
+            v = narrow<T>(mul(widen(A[(long)r * K + (k0 - blk + j)]), scale(rd, WR(-1))));
+        }
+        Aprev[e] = v;
     }
     for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)K * kAtomBlkMax; e += (long)gridDim.x * 256L) {
         const int r = (int)(e / kAtomBlkMax), j = (int)(e % kAtomBlkMax);
@@ -94,6 +111,17 @@ struct EpiAtomP {
     __device__ __forceinline__ void operator()(int r, int c, T v, int) const {
         const long i = (long)r * ld + c;
         out[i] = add(mul(sub(B[i], v), rden[r]), Dold[i]);
+    }
+};
+
+// out += acc   (the previous block's contribution to a look-ahead P)
+template <class T>
+struct EpiAddTo {
+    T* out;
+    long ld;
+    __device__ __forceinline__ void operator()(int r, int c, T v, int) const {
+        const long i = (long)r * ld + c;
+        out[i] = add(out[i], v);
     }
 };
 
@@ -233,7 +261,9 @@ constexpr size_t atom_recur_lds_bytes() {
 template <class T>
 struct AtomWs {
     T* Ablk = nullptr;   // [K, K]   every block's rows (prepared once per sweep)
-    T* P = nullptr;      // [64, F]
+    T* Alook = nullptr;  // [K, K]   the same with the previous block's columns zeroed
+    T* Aprev = nullptr;  // [K, 64]  -rden * A[block, previous block]
+    T* P = nullptr;      // 2 x [64, F]  (ping-pong: block b + 1 is prepared while block b is swept)
     T* G = nullptr;      // [64, 64]
     T* E = nullptr;      // [64, 64]
     T* Wl = nullptr;     // [K, 64]
@@ -246,7 +276,9 @@ struct AtomWs {
 template <class T>
 inline void atom_plan(WsPlan& p, int64_t F, int64_t K) {
     p.add<T>((size_t)K * K);
-    p.add<T>((size_t)kAtomBlkMax * F);
+    p.add<T>((size_t)K * K);
+    p.add<T>((size_t)K * kAtomBlkMax);
+    p.add<T>((size_t)2 * kAtomBlkMax * F);
     p.add<T>((size_t)kAtomBlkMax * kAtomBlkMax);
     p.add<T>((size_t)kAtomBlkMax * kAtomBlkMax);
     p.add<T>((size_t)K * kAtomBlkMax);
@@ -258,7 +290,9 @@ inline void atom_plan(WsPlan& p, int64_t F, int64_t K) {
 template <class T>
 inline int atom_carve(dcp_handle* h, AtomWs<T>& w, int64_t F, int64_t K) {
     w.Ablk = ws_alloc<T>(h, (size_t)K * K);
-    w.P = ws_alloc<T>(h, (size_t)kAtomBlkMax * F);
+    w.Alook = ws_alloc<T>(h, (size_t)K * K);
+    w.Aprev = ws_alloc<T>(h, (size_t)K * kAtomBlkMax);
+    w.P = ws_alloc<T>(h, (size_t)2 * kAtomBlkMax * F);
     w.G = ws_alloc<T>(h, (size_t)kAtomBlkMax * kAtomBlkMax);
     w.E = ws_alloc<T>(h, (size_t)kAtomBlkMax * kAtomBlkMax);
     w.Wl = ws_alloc<T>(h, (size_t)K * kAtomBlkMax);
@@ -269,7 +303,7 @@ inline int atom_carve(dcp_handle* h, AtomWs<T>& w, int64_t F, int64_t K) {
         w.ext = ws_alloc<real_t<T> >(h, (size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
         if (!w.ext) return fail(h, DCP_ERR_INTERNAL, "atom sweep workspace plan");
     }
-    if (!w.Ablk || !w.P || !w.G || !w.E || !w.Wl || !w.rden || !w.slabs)
+    if (!w.Ablk || !w.Alook || !w.Aprev || !w.P || !w.G || !w.E || !w.Wl || !w.rden || !w.slabs)
         return fail(h, DCP_ERR_INTERNAL, "atom sweep workspace plan");
     return DCP_OK;
 }
@@ -292,7 +326,7 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
     const int K = (int)K64, F = (int)F64;
     constexpr int BLK = atom_blk<T>();
     hipLaunchKernelGGL((atom_prep_kernel<T>), dim3(grid_for((long)K * K, 256)), dim3(256), 0, st, BLK, K, A,
-                       w.Ablk, w.Wl, w.rden);
+                       w.Ablk, w.Wl, w.rden, w.Alook, w.Aprev);
     DCP_LAUNCH_OK(h, hipGetLastError());
     {
         static DynLdsRaised raised;   // per dtype
@@ -306,20 +340,36 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
     }
     // The 64-row products of a block run on few CUs and are latency bound: 64-deep K blocks
     // (TILE_SMALL_DEEP) put 4x more loads in flight per barrier than the 16-deep small tile.
-    for (int k0 = 0; k0 < K; k0 += BLK) {
+    //
+    // Look-ahead: the recursion of block b is ONE workgroup, so the K-deep part of block b + 1's P
+    // (everything except block b's own atoms, which do not exist yet) runs on the side stream beside
+    // it; once D_new[block b] is there, its contribution is a 64-deep product added in place.
+    const int nblk = (K + BLK - 1) / BLK;
+    const bool lookahead = nblk > 1;
+    auto p_product = [&](hipStream_t s_, const T* Arows, int k0, int nb, T* Pout) -> int {
+        GemmArgs<T> a;   // P = (B_blk - Arows . D_cur) * rden + D_old[blk]
+        a.A = Arows + (long)k0 * K; a.lda = K; a.B = Dnew; a.ldb = F; a.M = nb; a.N = F; a.K = K;
+        a.tile = TILE_SMALL_DEEP;
+        a.ext_ws = w.ext;
+        DCP_LAUNCH_OK(h, (gemm<FORM_NN>(s_, a, EpiAtomP<T>{B + (long)k0 * F, Dnew + (long)k0 * F, w.rden + k0,
+                                                           Pout, (long)F})));
+        return DCP_OK;
+    };
+    {   // block 0: nothing to wait for
+        const int nb0 = K < BLK ? K : BLK;
+        DCP_TRY(p_product(st, w.Ablk, 0, nb0, w.P));
+    }
+    for (int b = 0; b < nblk; ++b) {
+        const int k0 = b * BLK;
         const int nb = (K - k0) < BLK ? (K - k0) : BLK;
-        const T* rden = w.rden + k0;
-        {   // (1) P = (B_blk - Ablk . D_cur) * rden + D_old[blk]
-            GemmArgs<T> a;
-            a.A = w.Ablk + (long)k0 * K; a.lda = K; a.B = Dnew; a.ldb = F; a.M = nb; a.N = F; a.K = K;
-            a.tile = TILE_SMALL_DEEP;
-            a.ext_ws = w.ext;
-            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiAtomP<T>{B + (long)k0 * F, Dnew + (long)k0 * F,
-                                                              rden, w.P, (long)F})));
-        }
+        T* P = w.P + (size_t)(b & 1) * kAtomBlkMax * F;
+        T* Pnext = w.P + (size_t)((b + 1) & 1) * kAtomBlkMax * F;
+        const bool has_next = (b + 1) < nblk;
+        const int k1 = k0 + BLK;
+        const int nb1 = has_next ? ((K - k1) < BLK ? (K - k1) : BLK) : 0;
         {   // (2) G = P P^H : one 64-deep K block per split
             GemmArgs<T> g;
-            g.A = w.P; g.lda = F; g.B = w.P; g.ldb = F; g.M = nb; g.N = nb; g.K = F;
+            g.A = P; g.lda = F; g.B = P; g.ldb = F; g.M = nb; g.N = nb; g.K = F;
             g.conjB = true;
             g.tile = TILE_SMALL_DEEP;
             g.ext_ws = w.ext;
@@ -330,16 +380,32 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
                                w.slabs, (long)nb * nb, g.ksplits, (long)nb * nb, w.G);
             DCP_LAUNCH_OK(h, hipGetLastError());
         }
+        if (has_next && lookahead) {
+            // side stream: P_next without block b's atoms.  It starts after everything enqueued so far
+            // (blocks < b are final in D_new; the complex path's ext scratch is free again) and reads
+            // block b's OLD rows only through zero weights.
+            DCP_TRY(side_after_main(h));
+            DCP_TRY(p_product(h->side, w.Alook, k1, nb1, Pnext));
+        }
         // (3) the b-step recursion in coefficient space
         hipLaunchKernelGGL((atom_recur_kernel<T>), dim3(1), dim3(256), atom_recur_lds_bytes<T>(), st, nb,
                            (const T*)w.G, (const T*)(w.Wl + (long)k0 * kAtomBlkMax), w.E);
         DCP_LAUNCH_OK(h, hipGetLastError());
+        if (has_next && lookahead) DCP_TRY(main_after_side(h));   // (also frees the ext scratch for (4))
         {   // (4) D_new[blk] = E . P
             GemmArgs<T> a;
-            a.A = w.E; a.lda = nb; a.B = w.P; a.ldb = F; a.M = nb; a.N = F; a.K = nb;
+            a.A = w.E; a.lda = nb; a.B = P; a.ldb = F; a.M = nb; a.N = F; a.K = nb;
             a.tile = TILE_SMALL_DEEP;
             a.ext_ws = w.ext;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiStore<T>{Dnew + (long)k0 * F, (long)F})));
+        }
+        if (has_next) {   // (5) P_next += Aprev[next block] . D_new[blk]
+            GemmArgs<T> a;
+            a.A = w.Aprev + (long)k1 * kAtomBlkMax; a.lda = kAtomBlkMax; a.B = Dnew + (long)k0 * F; a.ldb = F;
+            a.M = nb1; a.N = F; a.K = nb;
+            a.tile = TILE_SMALL_DEEP;
+            a.ext_ws = w.ext;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiAddTo<T>{Pnext, (long)F})));
         }
     }
     return DCP_OK;

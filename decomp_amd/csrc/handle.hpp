@@ -14,6 +14,11 @@ struct dcp_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t stream_switch = nullptr;   // orders the shared arena across dcp_set_stream changes
+    // Side stream for work that can run BESIDE a kernel that leaves most of the chip idle (the atom
+    // sweep's look-ahead product next to the one-workgroup recursion); created on first use and
+    // ordered against the main stream with events only (side_after_main / main_after_side).
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
     // Workspace: one grow-only arena.  A public call plans its total need, reserves it
     // (ws_reserve: reallocates only when the plan outgrows the arena, i.e. on the first
     // call of a given problem size, never in steady state), then bumps (ws_alloc).
@@ -86,6 +91,27 @@ struct ProfScope {
         h->prof_recs.push_back({label, a, b});
     }
 };
+
+// what is enqueued on h->side after this call starts after the work already on h->stream
+inline int side_after_main(dcp_handle* h) {
+    if (h->side == nullptr) {
+        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess)
+            return fail(h, DCP_ERR_HIP, "side stream creation failed");
+    }
+    if (hipEventRecord(h->ev_main, h->stream) != hipSuccess ||
+        hipStreamWaitEvent(h->side, h->ev_main, 0) != hipSuccess)
+        return fail(h, DCP_ERR_HIP, "side stream fork failed");
+    return DCP_OK;
+}
+// what is enqueued on h->stream after this call starts after the work already on h->side
+inline int main_after_side(dcp_handle* h) {
+    if (hipEventRecord(h->ev_side, h->side) != hipSuccess ||
+        hipStreamWaitEvent(h->stream, h->ev_side, 0) != hipSuccess)
+        return fail(h, DCP_ERR_HIP, "side stream join failed");
+    return DCP_OK;
+}
 
 inline void ws_reset(dcp_handle* h) {
     h->arena_used = 0;

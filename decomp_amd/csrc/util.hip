@@ -417,6 +417,12 @@ int dcp_destroy(dcp_handle* h) {
     }
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->stream_switch) (void)hipEventDestroy(h->stream_switch);
+    if (h->side) {
+        (void)hipStreamSynchronize(h->side);
+        (void)hipStreamDestroy(h->side);
+    }
+    if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     delete h;
     return DCP_OK;
 }
