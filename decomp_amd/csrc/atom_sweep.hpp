@@ -163,13 +163,12 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 constexpr int kAtomSub = 8;
 
 template <class T>
-__global__ void __launch_bounds__(256) atom_recur_kernel(int nb, const T* __restrict__ G,
-                                                         const T* __restrict__ Wl, T* __restrict__ E) {
+__device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int nb, const T* __restrict__ G,
+                                                const T* __restrict__ Wl, T* __restrict__ E) {
     typedef typename wide_of<T>::type WT;
     typedef real_t<WT> WR;
     constexpr int BMAX = atom_blk<T>();
     // 2 x BMAX^2 wide elements + BMAX^2 of T (80 KiB for float): dynamic LDS, see atom_recur_lds_bytes
-    extern __shared__ __attribute__((aligned(16))) unsigned char atom_lds_raw[];
     typedef WT (*Mat)[BMAX];
     typedef T (*MatT)[BMAX];
     Mat sE = reinterpret_cast<Mat>(atom_lds_raw);                              // row k: partial c_k, then E_k
@@ -254,6 +253,13 @@ __global__ void __launch_bounds__(256) atom_recur_kernel(int nb, const T* __rest
 }
 
 template <class T>
+__global__ void __launch_bounds__(256) atom_recur_kernel(int nb, const T* __restrict__ G,
+                                                         const T* __restrict__ Wl, T* __restrict__ E) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char atom_lds_dyn[];
+    atom_recur_body<T>(atom_lds_dyn, nb, G, Wl, E);
+}
+
+template <class T>
 constexpr size_t atom_recur_lds_bytes() {
     return (2 * sizeof(typename wide_of<T>::type) + sizeof(T)) * atom_blk<T>() * atom_blk<T>();
 }
@@ -273,6 +279,12 @@ struct AtomWs {
     real_t<T>* ext = nullptr;   // complex: real extended images (max(4KF, 4*64*F) reals)
 };
 
+// Gram slabs: up to 64 split-K slabs of the generic path, or one per 64-column tile of the fused float path
+inline size_t atom_slab_elems(int64_t F) {
+    const size_t n = (size_t)((F + 63) / 64);
+    return (n > 64 ? n : 64) * kAtomBlkMax * kAtomBlkMax;
+}
+
 template <class T>
 inline void atom_plan(WsPlan& p, int64_t F, int64_t K) {
     p.add<T>((size_t)K * K);
@@ -283,7 +295,7 @@ inline void atom_plan(WsPlan& p, int64_t F, int64_t K) {
     p.add<T>((size_t)kAtomBlkMax * kAtomBlkMax);
     p.add<T>((size_t)K * kAtomBlkMax);
     p.add<T>((size_t)K);
-    p.add<T>((size_t)64 * kAtomBlkMax * kAtomBlkMax);
+    p.add<T>(atom_slab_elems(F));
     if (scalar_traits<T>::is_complex) p.add<real_t<T> >((size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
 }
 
@@ -297,7 +309,7 @@ inline int atom_carve(dcp_handle* h, AtomWs<T>& w, int64_t F, int64_t K) {
     w.E = ws_alloc<T>(h, (size_t)kAtomBlkMax * kAtomBlkMax);
     w.Wl = ws_alloc<T>(h, (size_t)K * kAtomBlkMax);
     w.rden = ws_alloc<T>(h, (size_t)K);
-    w.slab_count = (size_t)64 * kAtomBlkMax * kAtomBlkMax;
+    w.slab_count = atom_slab_elems(F);
     w.slabs = ws_alloc<T>(h, w.slab_count);
     if (scalar_traits<T>::is_complex) {
         w.ext = ws_alloc<real_t<T> >(h, (size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);

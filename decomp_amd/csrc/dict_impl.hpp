@@ -12,6 +12,7 @@
 // (atom_sweep.hpp).
 #pragma once
 #include "atom_sweep.hpp"
+#include "atom_fused_f32.hpp"
 #include "lasso_impl.hpp"
 
 namespace dcp {
@@ -190,8 +191,13 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
                        stats, (long)K, (long)F, beta, A, B);
     DCP_LAUNCH_OK(h, hipGetLastError());
     DCP_HIP_OK(h, hipMemcpyAsync(Dnew, D, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice, st));
-    // blocked atom sweep
-    DCP_TRY(atom_sweep<T>(h, A, B, Dnew, F, K, w.atom));
+    // blocked atom sweep (float32 with K, F multiples of 64: the fused three-launch path)
+    bool fused = false;
+    if constexpr (std::is_same<T, float>::value) {
+        fused = atom_fused_ok(F, K);
+        if (fused) DCP_TRY(atom_sweep_fused_f32(h, A, B, Dnew, F, K, w.atom));
+    }
+    if (!fused) DCP_TRY(atom_sweep<T>(h, A, B, Dnew, F, K, w.atom));
     const int mb = grid_for((long)K * F, 256);
     hipLaunchKernelGGL((maxabsdiff_partial_kernel<T>), dim3(mb), dim3(256), 0, st, D, (const T*)Dnew,
                        (long)K * F, w.partial);

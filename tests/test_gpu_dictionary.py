@@ -82,9 +82,13 @@ def test_golden_single_precision_and_wide(name):
     assert _err(x, xg) < tol_x, (name, _err(x, xg))
 
 
-@pytest.mark.parametrize('dt,K', [('float64', 160), ('float32', 160), ('float64', 200),
-                                  ('complex128', 80), ('complex64', 80), ('float64', 64), ('float32', 33)])
-def test_atom_sweep_direct_against_oracle(dt, K):
+@pytest.mark.parametrize('dt,K,F', [('float64', 160, 96), ('float32', 160, 96), ('float64', 200, 96),
+                                    ('complex128', 80, 96), ('complex64', 80, 96), ('float64', 64, 96),
+                                    ('float32', 33, 96),
+                                    # float32 with K, F multiples of 64: the fused three-launch path
+                                    # (csrc/atom_fused_f32.hpp), 1 / 3 / 4 blocks
+                                    ('float32', 64, 128), ('float32', 192, 128), ('float32', 256, 320)])
+def test_atom_sweep_direct_against_oracle(dt, K, F):
     """dcp_dict_update_* alone (A/B accumulation + the blocked Gauss-Seidel atom sweep + max|dD|)
     against oracle.dictionary_learning.atom_sweep (dictionary_learning.py:154-159) for dictionaries
     wider than one 64-atom block, incl. a tail block and a zero code column (the A_kk + 1e-15
@@ -96,7 +100,7 @@ def test_atom_sweep_direct_against_oracle(dt, K):
     from oracle.common import l2_strict
     rng = np.random.RandomState(K)
     cplx = dt.startswith('complex')
-    Nb, F = 300, 96
+    Nb = 300
 
     def randn(*s):
         return (rng.randn(*s) + 1j * rng.randn(*s)) if cplx else rng.randn(*s)
