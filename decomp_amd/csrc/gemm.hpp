@@ -319,22 +319,38 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
 // ------------------------------------------------------------------ epilogues ----
 // All are called as epi(row, col, acc, split).
 
+inline bool al16_ptr(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
 template <class T>
 struct EpiStore {  // C[row, col] = acc
+    // 16-byte epilogue available but OFF (interleaved in-process A/B, tools/vec_ab.py): x.D 16384x4096x256
+    // 0.326 ms with it, 0.318 without: for a pure store the quad transposes cost as much VALU issue as the
+    // narrower stores save.  It pays where the epilogue also LOADS per element (EpiMuNum: 1.045 -> 1.010 ms
+    // on the dominant kernel).
+    static constexpr bool kVec4 = false;
     T* C;
     long ldc;
     __device__ __forceinline__ void operator()(int r, int c, T v, int) const {
         C[(long)r * ldc + c] = v;
     }
+    bool vec_ok() const { return al16_ptr(C) && (ldc % 4) == 0; }
+    __device__ __forceinline__ void vec4(int r, int c0, f32x4 v, int) const {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + (long)r * ldc + c0) = v;
+    }
 };
 
 template <class T>
 struct EpiSlab {  // split-K partial: slab[split][row, col] = acc
+    static constexpr bool kVec4 = false;   // neutral in the A/B (1.134 vs 1.130 ms on x^T.Y): off
     T* slab;
     long ldc;
     long slab_stride;
     __device__ __forceinline__ void operator()(int r, int c, T v, int s) const {
         slab[(long)s * slab_stride + (long)r * ldc + c] = v;
+    }
+    bool vec_ok() const { return al16_ptr(slab) && (ldc % 4) == 0 && (slab_stride % 4) == 0; }
+    __device__ __forceinline__ void vec4(int r, int c0, f32x4 v, int s) const {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(slab) + (long)s * slab_stride + (long)r * ldc + c0) = v;
     }
 };
 
@@ -343,6 +359,7 @@ struct EpiSlab {  // split-K partial: slab[split][row, col] = acc
 // or one value per column (ld_den == 0), e.g. KL's colsum(D).
 template <class T>
 struct EpiMuNum {
+    static constexpr bool kVec4 = std::is_same<T, float>::value;
     const T* cur;
     long ld_cur;
     const T* den;
@@ -353,6 +370,19 @@ struct EpiMuNum {
         const T d = den[(long)r * ld_den + c];
         out[(long)r * ld_out + c] = cur[(long)r * ld_cur + c] * max_np(v, T(0)) /
                                     max_np(d, T(1.0e-15));
+    }
+    // (ld_den == 0: one denominator per column, read as 4 consecutive values of the vector)
+    bool vec_ok() const {
+        return al16_ptr(cur) && al16_ptr(den) && al16_ptr(out) && (ld_cur % 4) == 0 && (ld_den % 4) == 0 &&
+               (ld_out % 4) == 0;
+    }
+    __device__ __forceinline__ void vec4(int r, int c0, f32x4 v, int) const {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(den) + (long)r * ld_den + c0);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(cur) + (long)r * ld_cur + c0);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = x[e] * max_np(v[e], 0.0f) / max_np(d[e], 1.0e-15f);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (long)r * ld_out + c0) = o;
     }
 };
 

@@ -34,6 +34,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace dcp {
 
@@ -55,6 +56,7 @@ struct GemmProblem {
     int tiles_m, tiles_n;
     int tiles_n1;  // n tiles that belong to the first B segment (tiles never straddle)
     int mt_fast;   // 1: consecutive logical ids walk m tiles first
+    int vec_epi;   // set by the launcher: the functor's 16-byte epilogue (vec4) may be used
 };
 
 // PIPE_ = 1: the per-block barrier sits between the MFMA groups of a K block (operands of the
@@ -98,6 +100,48 @@ template <class E, class = void>
 struct epi_rowbits { static constexpr bool value = false; };
 template <class E>
 struct epi_rowbits<E, decltype((void)E::kRowBits)> { static constexpr bool value = E::kRowBits; };
+
+// Epilogue functors may carry `static constexpr bool kVec4 = true` together with
+//     bool vec_ok() const                      (host: every array 16-byte aligned, leading dims % 4 == 0)
+//     void vec4(int row, int col0, f32x4 v, int split) const      (columns col0 .. col0 + 3 of one row)
+// The 32x32 accumulator holds a COLUMN per lane (4 consecutive rows in registers 4g .. 4g+3); a 4x4
+// transpose inside every lane quad (two DPP quad_perm exchanges) turns that into 4 consecutive columns
+// of one row per lane, so the epilogue moves 16 bytes per lane and instruction: 4x fewer loads / stores
+// and address computations than the per-element form (the epilogue is store-issue bound, guide T21).
+template <class E, class = void>
+struct epi_vec4 { static constexpr bool value = false; };
+template <class E>
+struct epi_vec4<E, decltype((void)E::kVec4)> { static constexpr bool value = E::kVec4; };
+
+template <class E>
+inline bool epi_vec_ok(const E& e) {
+    if constexpr (epi_vec4<E>::value) return e.vec_ok();
+    else return false;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float quad_perm_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// x[j] = element (row j, column of lane t) of a 4x4 block held by the lane quad  ->  element (row t, column j)
+__device__ __forceinline__ f32x4 quad_transpose(f32x4 x, int t) {
+    const bool odd = t & 1, hi = t & 2;
+    const float n0 = quad_perm_f32<0xB1>(x[0]), n1 = quad_perm_f32<0xB1>(x[1]);      // lanes t ^ 1
+    const float n2 = quad_perm_f32<0xB1>(x[2]), n3 = quad_perm_f32<0xB1>(x[3]);
+    f32x4 z;
+    z[0] = odd ? n1 : x[0];
+    z[1] = odd ? x[1] : n0;
+    z[2] = odd ? n3 : x[2];
+    z[3] = odd ? x[3] : n2;
+    const float m0 = quad_perm_f32<0x4E>(z[0]), m1 = quad_perm_f32<0x4E>(z[1]);      // lanes t ^ 2
+    const float m2 = quad_perm_f32<0x4E>(z[2]), m3 = quad_perm_f32<0x4E>(z[3]);
+    f32x4 y;
+    y[0] = hi ? m2 : z[0];
+    y[1] = hi ? m3 : z[1];
+    y[2] = hi ? z[2] : m0;
+    y[3] = hi ? z[3] : m1;
+    return y;
+}
 
 template <int LAY, int ROWS, int BK, int NT = 256, int MF = 32>
 struct PanelGeom {
@@ -528,6 +572,26 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     //      (rr ri; ir ii) sits in registers r, r+1 of lanes 2q, 2q+1:
     //      re = rr + ii, im = ri - ir  (two shuffles), even lanes call the complex functor
     constexpr int MODE = epi_mode<Epi>::value;
+    if constexpr (MODE == 0 && !EDGE && !ROWBITS && epi_vec4<Epi>::value) {
+        if (p.vec_epi) {
+            const int t = l31 & 3, col0 = (l31 & ~3);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 x;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            x[e] = acc[i][j][4 * g + e];
+                        }
+                        const f32x4 y = quad_transpose(x, t);
+                        epi.vec4(m0 + wm * WM + i * 32 + 8 * g + 4 * h + t, n0 + wn * WN + j * 32 + col0, y, split);
+                    }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -597,6 +661,7 @@ inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi&
     bool fast = (p.M % BM == 0) && (p.N % BN == 0) && (p.K % BK == 0) && (p.klen % BK == 0) &&
                 (p.lda % 4 == 0) && (p.ldb % 4 == 0) && al16(p.A) && al16(p.B) && p.K > 0;
     if (p.B2 != nullptr) fast = fast && (p.n_b1 % BN == 0) && (p.ldb2 % 4 == 0) && al16(p.B2);
+    p.vec_epi = (fast && epi_vec_ok(epi)) ? 1 : 0;
     const int grid = p.tiles_m * p.tiles_n * p.ksplits;
     if (grid <= 0) return hipSuccess;
     constexpr int lds_bytes = 8 * (PanelGeom<ALAY, BM, BK, Cfg::NTHREADS>::ELEMS +
