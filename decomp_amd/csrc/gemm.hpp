@@ -412,6 +412,17 @@ struct EpiMulMask {
     __device__ __forceinline__ void operator()(int r, int c, T v, int) const {
         out[(long)r * ld_out + c] = scale(v, mask[(long)r * ld_mask + c]);
     }
+    static constexpr bool kVec4 = std::is_same<T, float>::value;   // one load per element: 16-byte form
+    bool vec_ok() const { return al16_ptr(mask) && al16_ptr(out) && (ld_mask % 4) == 0 && (ld_out % 4) == 0; }
+    __device__ __forceinline__ void vec4(int r, int c0, f32x4 v, int) const {
+        if constexpr (std::is_same<T, float>::value) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (long)r * ld_mask + c0);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[e] * m[e];
+            *reinterpret_cast<f32x4*>(out + (long)r * ld_out + c0) = o;
+        }
+    }
 };
 
 // out = acc * mask for a BINARY mask handed over as row bits (see epi_rowbits in gemm_mfma_f32.hpp):
@@ -445,6 +456,25 @@ struct EpiKlRatio {
         T yy = y[(long)r * ld_y + c];
         if (mask != nullptr) yy = yy * mask[(long)r * ld_mask + c];
         out[(long)r * ld_out + c] = yy / (v + T(1.0e-15));
+    }
+    static constexpr bool kVec4 = std::is_same<T, float>::value;
+    bool vec_ok() const {
+        return al16_ptr(y) && al16_ptr(out) && (ld_y % 4) == 0 && (ld_out % 4) == 0 &&
+               (mask == nullptr || (al16_ptr(mask) && (ld_mask % 4) == 0));
+    }
+    __device__ __forceinline__ void vec4(int r, int c0, f32x4 v, int) const {
+        if constexpr (std::is_same<T, float>::value) {
+            f32x4 yy = *reinterpret_cast<const f32x4*>(y + (long)r * ld_y + c0);
+            if (mask != nullptr) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (long)r * ld_mask + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yy[e] = yy[e] * m[e];
+            }
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = yy[e] / (v[e] + 1.0e-15f);
+            *reinterpret_cast<f32x4*>(out + (long)r * ld_out + c0) = o;
+        }
     }
 };
 
