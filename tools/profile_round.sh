@@ -2,7 +2,8 @@
 # Run on the GPU box (through gpurun): rocprofv3 kernel trace + PMC passes of bench.py.
 # Usage: tools/profile_round.sh <tag>   -> gpurun_out/prof_<tag>/...
 set -u
-TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
