@@ -135,3 +135,29 @@ def test_errors():
     # maxiter exhaustion returns maxiter - 1
     it, x = lasso.solve(y, A, 0.1, tol=0.0, maxiter=13, method='fista')
     assert it == 12
+
+
+@pytest.mark.parametrize('method', ['ista', 'acc_ista', 'fista', 'ista_pos'])
+@pytest.mark.parametrize('mask_kind', ['mask2d', 'mask1d'])
+def test_masked_against_oracle_medium_fp32(method, mask_kind):
+    """float32 with a mask at tile-aligned sizes (2048 x 384, K = 192), i.e. through the fast-path
+    kernels and their 16-byte epilogues: the chained (v A o M) A^H product with the per-row threshold
+    scale (2-D mask, lasso.py:306-328) and the folded 1-D mask, against the oracle."""
+    from decomp_amd import lasso
+    from oracle import lasso as olasso
+    rng = np.random.RandomState(11)
+    N, F, K = 2048, 384, 192
+    A = rng.randn(K, F).astype(np.float32)
+    xt = (rng.randn(N, K) * (rng.uniform(size=(N, K)) < 0.05))
+    if method.endswith('_pos'):
+        xt = np.abs(xt)
+    y = (xt @ A + 0.1 * rng.randn(N, F)).astype(np.float32)
+    if mask_kind == 'mask2d':
+        mask = (rng.uniform(size=(N, F)) > 0.25).astype(np.float32)
+    else:
+        mask = (rng.uniform(size=F) > 0.25).astype(np.float32)
+    it, x = lasso.solve(y, A, 0.05, tol=1e-9, method=method, maxiter=25, mask=mask.copy())
+    ito, xo = olasso.solve(y.copy(), A.copy(), 0.05, tol=1e-9, method=method, maxiter=25, mask=mask.copy())
+    assert it == ito
+    assert _err(x, xo) < 2e-4, _err(x, xo)
+    assert np.count_nonzero(x) > 0
