@@ -28,6 +28,9 @@ struct GemmArgs {
     const T* B2 = nullptr;  // optional second column segment of B (columns >= n_b1)
     long ldb2 = 0;
     int n_b1 = 0;
+    const T* A2 = nullptr;  // optional second ROW segment of A (rows >= m_a1); float32 MFMA core only
+    long lda2 = 0;
+    int m_a1 = 0;
     int M = 0, N = 0, K = 0;
     int ksplits = 1;  // >1: split the reduction; the epilogue sees the split index
     int klen = 0;     // reduction length per split (set by plan_splits)
@@ -191,6 +194,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         GemmProblem p;
         p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb;
         p.B2 = a.B2; p.ldb2 = a.ldb2; p.n_b1 = a.n_b1;
+        p.A2 = a.A2; p.lda2 = a.lda2; p.m_a1 = a.m_a1;
         p.M = a.M; p.N = a.N; p.K = a.K;
         p.ksplits = a.ksplits; p.klen = a.klen;
         p.tiles_m = p.tiles_n = 0;

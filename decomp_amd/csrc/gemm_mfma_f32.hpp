@@ -51,10 +51,14 @@ struct GemmProblem {
     const float* B2;  // columns [n_b1, N) (optional second segment), may be null
     long ldb2;
     int n_b1;
+    const float* A2 = nullptr;  // rows [m_a1, M) of A (optional second ROW segment: two products against
+    long lda2 = 0;              // one B in a single launch, e.g. [f ; Y o M] . D^T), may be null
+    int m_a1 = 0;
     int M, N, K;
     int ksplits, klen;
     int tiles_m, tiles_n;
     int tiles_n1;  // n tiles that belong to the first B segment (tiles never straddle)
+    int tiles_m1;  // m tiles that belong to the first A segment
     int mt_fast;   // 1: consecutive logical ids walk m tiles first
     int vec_epi;   // set by the launcher: the functor's 16-byte epilogue (vec4) may be used
 };
@@ -295,7 +299,17 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
         nt = t % p.tiles_n;
         mt = t / p.tiles_n;
     }
-    const int m0 = mt * BM;
+    const int m0 = mt * BM;     // first OUTPUT row of this tile
+    // A may be two row segments stacked (each with its own run of m tiles)
+    const float* Ap = p.A;
+    long lda = p.lda;
+    int mA0 = m0, nArows = p.m_a1;
+    if (mt >= p.tiles_m1) {
+        Ap = p.A2;
+        lda = p.lda2;
+        mA0 = (mt - p.tiles_m1) * BM;
+        nArows = p.M - p.m_a1;
+    }
     const int kbeg = split * p.klen;
     const int kend = min(p.K, kbeg + p.klen);
 
@@ -330,7 +344,7 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
         f32x4 ra[GA::F4], rb[GB::F4];
         const int nkb = (kend - kbeg + BK - 1) / BK;
         if (nkb > 0) {
-            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, kbeg, kend, tid);
             panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
             panel_lds_store<ALAY, BM, BK, NT, MF>(sA0, ra, tid);
             panel_lds_store<BLAY, BN, BK, NT, MF>(sB0, rb, tid);
@@ -343,7 +357,7 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
             const bool more = (kb + 1) < nkb;
             if (more) {
                 const int k0 = kbeg + (kb + 1) * BK;
-                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid);
                 panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
             }
             f32x4 fa[T16M], fb[T16N];
@@ -405,7 +419,7 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     const int nkb = (kend - kbeg + BK - 1) / BK;
 
     if (nkb > 0) {
-        panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+        panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, kbeg, kend, tid);
         panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
         panel_lds_store<ALAY, BM, BK, NT, MF>(sA0, ra, tid);
         panel_lds_store<BLAY, BN, BK, NT, MF>(sB0, rb, tid);
@@ -435,7 +449,7 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
             }
             if (more) {  // next block's global loads, behind the LDS reads in issue order
                 const int k0 = kbeg + (kb + 1) * BK;
-                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid);
                 panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -463,7 +477,7 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
             const bool more = (kb + 1) < nkb;
             if (more) {  // issue next block's global loads; they land during the MFMAs
                 const int k0 = kbeg + (kb + 1) * BK;
-                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid);
                 panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
             }
     #pragma unroll
@@ -506,7 +520,7 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
             for (int j = 0; j < TN; ++j) fb[j] = panel_frag<BLAY, BN, BK>(sB0, wn * WN + j * 32 + l31, 0, h);
         }
         if (nkb > 1) {
-            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, kbeg + BK, kend, tid);
+            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, kbeg + BK, kend, tid);
             panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg + BK, kend, tid);
         }
         for (int kb = 0; kb < nkb; ++kb) {
@@ -532,7 +546,7 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
                     __syncthreads();
                     if ((kb + 2) < nkb) {
                         const int k0 = kbeg + (kb + 2) * BK;
-                        panel_gload<ALAY, BM, BK, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+                        panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid);
                         panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
                     }
                     if (more) {
@@ -648,7 +662,9 @@ template <class Cfg, int ALAY, int BLAY, class Epi>
 inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi& epi) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
     if (p.B2 == nullptr) p.n_b1 = p.N;
-    p.tiles_m = (p.M + BM - 1) / BM;
+    if (p.A2 == nullptr) p.m_a1 = p.M;
+    p.tiles_m1 = (p.m_a1 + BM - 1) / BM;
+    p.tiles_m = p.tiles_m1 + (p.M - p.m_a1 + BM - 1) / BM;
     p.tiles_n1 = (p.n_b1 + BN - 1) / BN;
     p.tiles_n = p.tiles_n1 + (p.N - p.n_b1 + BN - 1) / BN;
     if (p.ksplits < 1) p.ksplits = 1;
@@ -661,6 +677,7 @@ inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi&
     bool fast = (p.M % BM == 0) && (p.N % BN == 0) && (p.K % BK == 0) && (p.klen % BK == 0) &&
                 (p.lda % 4 == 0) && (p.ldb % 4 == 0) && al16(p.A) && al16(p.B) && p.K > 0;
     if (p.B2 != nullptr) fast = fast && (p.n_b1 % BN == 0) && (p.ldb2 % 4 == 0) && al16(p.B2);
+    if (p.A2 != nullptr) fast = fast && (p.m_a1 % BM == 0) && (p.lda2 % 4 == 0) && al16(p.A2);
     p.vec_epi = (fast && epi_vec_ok(epi)) ? 1 : 0;
     const int grid = p.tiles_m * p.tiles_n * p.ksplits;
     if (grid <= 0) return hipSuccess;

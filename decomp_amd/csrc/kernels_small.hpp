@@ -187,6 +187,22 @@ __global__ void __launch_bounds__(256) mu_quotient_slabs_kernel(const T* __restr
     }
 }
 
+// The MU quotient for the STACKED split-K product [den ; num] (rows [0, count) of every slab hold the
+// negative part, rows [count, 2 count) the positive part): out = cur * max(sum num, 0) / max(sum den, eps).
+template <class T>
+__global__ void __launch_bounds__(256) mu_quotient_stacked_kernel(const T* __restrict__ cur,
+                                                                  const T* __restrict__ slabs, long stride,
+                                                                  int S, long count, T* __restrict__ out) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < count; i += (long)gridDim.x * 256L) {
+        T de = slabs[i], nu = slabs[count + i];
+        for (int s = 1; s < S; ++s) {
+            de = de + slabs[(long)s * stride + i];
+            nu = nu + slabs[(long)s * stride + count + i];
+        }
+        out[i] = cur[i] * max_np(nu, T(0)) / max_np(de, T(1.0e-15));
+    }
+}
+
 // One workgroup per row of U[K, F]:  out = U / sqrt(sum |U|^2)  (strict) or
 // U / sqrt(max(sum |U|^2, 1)).  Optionally block-max of |ref - out| into rowmax[row].
 template <class T>

@@ -87,6 +87,12 @@ inline size_t nmf_slab_elems(const NmfShape<T>& s) {
     GemmArgs<T> pg;
     const int ps = nmf_xupdate_splits<T>(s.N, s.F, s.K, pg);
     size_t x_slabs = ps > 1 ? (size_t)ps * s.N * s.K : 0;
+    if (ps > 1 && s.masked && s.lik == DCP_LIK_L2) {      // the stacked [f ; Y o M] . D^T launch
+        GemmArgs<T> sg;
+        const int ss = nmf_xupdate_splits<T>(2 * s.N, s.F, s.K, sg);
+        const size_t st_slabs = (size_t)(ss > 1 ? ss : 1) * 2 * s.N * s.K;
+        if (st_slabs > x_slabs) x_slabs = st_slabs;
+    }
     size_t m = stats_slabs > g_slabs ? stats_slabs : g_slabs;
     return m > x_slabs ? m : x_slabs;
 }
@@ -192,6 +198,7 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
     };
 
     const T* X = Xin;
+    bool x_done = false;
     if (phases & 1) {
     // ---------------- x <- x * max(pos,0) / max(neg,eps) ----------------
     const T* xnum_A = Ypre;   // left operand of the positive-part GEMM (. D^T)
@@ -216,10 +223,36 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
         }
     } else if (s.lik == DCP_LIK_L2) {
         DCP_TRY(forward(Xin));
-        ProfScope ps(h, DCP_PROF_XNEG);   // Q = f D^T
-        GemmArgs<T> q;
-        q.A = w.f; q.lda = F; q.B = D; q.ldb = F; q.M = N; q.N = K; q.K = F;
-        DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, q, EpiStore<T>{w.Q, K})));
+        if constexpr (std::is_same<T, float>::value) {
+            // masked l2 with few rows per GPU: both parts of the x gradient are products against the
+            // same D^T -- [f ; Y o M] . D^T as ONE split-K launch over the stacked rows (2N x K output:
+            // twice the tiles, half the splits, one set of fixed costs), then one quotient kernel
+            GemmArgs<T> sg;
+            sg.A = w.f; sg.lda = F; sg.A2 = Ypre; sg.lda2 = F; sg.m_a1 = N;
+            sg.B = D; sg.ldb = F; sg.M = 2 * N; sg.N = K; sg.K = F;
+            GemmArgs<T> probe;
+            const bool split_single = nmf_xupdate_splits<T>(s.N, s.F, s.K, probe) > 1;
+            if (split_single && (N % 256) == 0 && (F % 16) == 0) {
+                ProfScope ps(h, DCP_PROF_XUPDATE);
+                nmf_xupdate_splits<T>(2 * s.N, s.F, s.K, sg);      // plan for the stacked problem
+                sg.A = w.f; sg.lda = F; sg.A2 = Ypre; sg.lda2 = F; sg.m_a1 = N;
+                sg.B = D; sg.ldb = F;
+                if (sg.ksplits < 1) sg.ksplits = 1;
+                if ((size_t)sg.ksplits * 2 * N * K > w.slab_count)
+                    return fail(h, DCP_ERR_INTERNAL, "nmf stacked x-update slab plan mismatch");
+                DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, sg, EpiSlab<T>{w.slabs, K, (long)2 * N * K})));
+                hipLaunchKernelGGL((mu_quotient_stacked_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0,
+                                   st, Xin, (const T*)w.slabs, (long)2 * N * K, sg.ksplits, (long)N * K, Xout);
+                DCP_LAUNCH_OK(h, hipGetLastError());
+                x_done = true;
+            }
+        }
+        if (!x_done) {
+            ProfScope ps(h, DCP_PROF_XNEG);   // Q = f D^T
+            GemmArgs<T> q;
+            q.A = w.f; q.lda = F; q.B = D; q.ldb = F; q.M = N; q.N = K; q.K = F;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, q, EpiStore<T>{w.Q, K})));
+        }
     } else {
         DCP_TRY(forward(Xin));
         xnum_A = w.f;
@@ -236,7 +269,7 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
             DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, q, EpiStore<T>{w.Q, K})));
         }
     }
-    {   // x <- x * max(pos, 0) / max(neg, eps)
+    if (!x_done) {   // x <- x * max(pos, 0) / max(neg, eps)
         ProfScope ps(h, DCP_PROF_XUPDATE);
         GemmArgs<T> pg;
         pg.A = xnum_A; pg.lda = F; pg.B = D; pg.ldb = F; pg.M = N; pg.N = K; pg.K = F;
