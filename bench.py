@@ -265,6 +265,48 @@ def secondary_configs(torch, device):
     W = 4.0 * N * K * F + 4.0 * N * K * K + 4.0 * K * K * F
     out['f64_nmf_ms_per_iter'] = {'workload': '16384x4096 k=256 float64', 'value': round(ms, 4),
                                   'tflops': round(W / ms / 1e9, 1), 'fp64_peak': 78.6}
+    del Yd, Dd, xd, mask
+    # one 8192-row shard of configs[1] (what each GPU of an 8-GPU run computes per step, no collective)
+    Ns = 8192
+    Ys, xs = Y[:Ns].contiguous(), torch.ones((Ns, K), device=device)
+    Ds = D.clone()
+
+    def shard(n=10):
+        _hip.check(h, lib.dcp_nmf_mu_f32(h, _arrays.ptr(Ys), None, _arrays.ptr(xs), _arrays.ptr(Ds), Ns, F, K,
+                                         _hip.LIK_L2, ctypes.c_float(0.0), n + 1, ctypes.byref(it), None, None),
+                   'nmf_mu shard')
+    ms = ms_of(shard, 3) / 10
+    Ws = 4.0 * Ns * K * F + 4.0 * Ns * K * K + 4.0 * K * K * F
+    out['shard_8192_rows_ms_per_iter'] = {'workload': 'one 8192-row shard of configs[1] on one GPU, no collective',
+                                          'value': round(ms, 4), 'tflops': round(Ws / ms / 1e9, 1),
+                                          'compute_side_speedup_at_8_gpus': None}
+    del Y, Ys, xs, Ds, x
+    # configs[4]: one complex64 dictionary-learning minibatch step at one GPU's shape, 8192 x 8192, k = 512
+    MB, F, K = 8192, 8192, 512
+
+    def crandn(*sh):
+        return torch.complex(torch.randn(sh, generator=g, device=device), torch.randn(sh, generator=g, device=device))
+    Dt = crandn(K, F)
+    xt = 30.0 * crandn(MB, K) * (torch.rand((MB, K), generator=g, device=device) < 0.05)
+    Yc = xt @ Dt + 0.1 * crandn(MB, F)
+    Dc = Dt + 0.2 * crandn(K, F)
+    del xt, Dt
+    _arrays.l2_normalize_(Dc, strict=True)
+    xc = torch.ones((MB, K), device=device, dtype=torch.complex64)
+    Ac = torch.zeros((K, K), device=device, dtype=torch.complex64)
+    Bc = torch.zeros((K, F), device=device, dtype=torch.complex64)
+    cstate = {'D': Dc, 'Dn': torch.empty_like(Dc), 'count': 0}
+
+    def dl_c64():
+        theta = cstate['count'] * MB + 1.0
+        _hip.check(h, lib.dcp_dict_step_c64(h, _arrays.ptr(Yc), _arrays.ptr(xc), _arrays.ptr(cstate['D']),
+                                            _arrays.ptr(cstate['Dn']), _arrays.ptr(Ac), _arrays.ptr(Bc), MB, F, K,
+                                            (theta - MB) / theta, 0.1, _hip.LASSO_ISTA, 10, 1e-5,
+                                            ctypes.byref(md), ctypes.byref(lit)), 'dict_step c64')
+        cstate['D'], cstate['Dn'] = cstate['Dn'], cstate['D']
+        cstate['count'] += 1
+    out['complex_dictionary_step_ms'] = {'workload': 'configs[4] minibatch 8192x8192 complex64 k=512 ista x10',
+                                         'value': round(ms_of(dl_c64, 4), 4)}
     return out
 
 
@@ -435,6 +477,9 @@ def main():
                 del Y
                 torch.cuda.empty_cache()
                 out['secondary'] = secondary_configs(torch, device)
+                sh = out['secondary'].get('shard_8192_rows_ms_per_iter')
+                if sh:      # the full problem's step against one of its eight shards (before the all-reduce)
+                    sh['compute_side_speedup_at_8_gpus'] = round(ms_step / sh['value'], 2)
             except Exception as e:      # never lose the headline line to a side measurement
                 out['secondary'] = {'error': repr(e)}
         print(json.dumps(out))
