@@ -406,6 +406,49 @@ struct EpiMuDen {
     }
 };
 
+// Split-K numerator: out = cur * max(sum_s slab_s, 0) / max(acc, 1e-15).  acc is the NEGATIVE part (x.G);
+// the positive part (Y.D^T) arrives as S ordered split-K partials, summed here in the fixed order
+// 0..S-1 (as mu_quotient_slabs_kernel does).  With few rows per GPU the Y.D^T product splits its
+// reduction; the quotient then rides on the x.G product (16-byte epilogue) instead of a pass of its own.
+template <class T>
+struct EpiMuDenSlabs {
+    static constexpr bool kVec4 = std::is_same<T, float>::value;
+    const T* cur;
+    long ld_cur;
+    const T* slabs;      // [S][rows, ld_slab]
+    long ld_slab;
+    long slab_stride;
+    int S;
+    T* out;
+    long ld_out;
+    __device__ __forceinline__ void operator()(int r, int c, T v, int) const {
+        const long o = (long)r * ld_slab + c;
+        T nu = slabs[o];
+        for (int s = 1; s < S; ++s) nu = nu + slabs[(long)s * slab_stride + o];
+        out[(long)r * ld_out + c] = cur[(long)r * ld_cur + c] * max_np(nu, T(0)) / max_np(v, T(1.0e-15));
+    }
+    bool vec_ok() const {
+        return al16_ptr(cur) && al16_ptr(slabs) && al16_ptr(out) && (ld_cur % 4) == 0 && (ld_slab % 4) == 0 &&
+               (slab_stride % 4) == 0 && (ld_out % 4) == 0;
+    }
+    __device__ __forceinline__ void vec4(int r, int c0, f32x4 v, int) const {
+        if constexpr (std::is_same<T, float>::value) {
+            const long o = (long)r * ld_slab + c0;
+            f32x4 nu = *reinterpret_cast<const f32x4*>(slabs + o);
+            for (int s = 1; s < S; ++s) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(slabs + (long)s * slab_stride + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) nu[e] = nu[e] + p[e];
+            }
+            const f32x4 x = *reinterpret_cast<const f32x4*>(cur + (long)r * ld_cur + c0);
+            f32x4 q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = x[e] * max_np(nu[e], 0.0f) / max_np(v[e], 1.0e-15f);
+            *reinterpret_cast<f32x4*>(out + (long)r * ld_out + c0) = q;
+        }
+    }
+};
+
 // out = acc * mask  (f = (x.D) o M, grads.py:113,123)
 template <class T>
 struct EpiMulMask {

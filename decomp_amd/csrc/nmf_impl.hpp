@@ -204,6 +204,12 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
     const T* xnum_A = Ypre;   // left operand of the positive-part GEMM (. D^T)
     const T* xden = w.Q;      // negative part
     long ld_xden = K;
+    // Few rows per GPU (one shard of a multi-GPU run): Y.D^T splits its F reduction so that all CUs work, and
+    // the quotient moves into the 16-byte epilogue of the x.G product, which then runs AFTER it (float32).
+    // Not for an in-place update: that product reads whole rows of x while other tiles write them.
+    GemmArgs<T> pg_probe;
+    const bool split_gram = gram && std::is_same<T, float>::value && Xout != Xin &&
+                            nmf_xupdate_splits<T>(s.N, s.F, s.K, pg_probe) > 1;
     if (gram) {
         {   // G = D D^T  (split over F, partial slabs summed in order)
             ProfScope ps(h, DCP_PROF_GRAM);
@@ -215,7 +221,7 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
                                st, w.slabs, (long)K * K, g.ksplits, (long)K * K, w.G);
             DCP_LAUNCH_OK(h, hipGetLastError());
         }
-        {   // Q = x G
+        if (!split_gram) {   // Q = x G
             ProfScope ps(h, DCP_PROF_XNEG);
             GemmArgs<T> q;
             q.A = Xin; q.lda = K; q.B = w.G; q.ldb = K; q.M = N; q.N = K; q.K = K;
@@ -284,10 +290,17 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
             if ((size_t)pg.ksplits * N * K > w.slab_count)
                 return fail(h, DCP_ERR_INTERNAL, "nmf x-update slab plan mismatch");
             DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, pg, EpiSlab<T>{w.slabs, K, (long)N * K})));
-            hipLaunchKernelGGL((mu_quotient_slabs_kernel<T>), dim3(grid_for((long)N * K)), dim3(256),
-                               0, st, Xin, (const T*)w.slabs, (long)N * K, pg.ksplits, xden,
-                               (long)ld_xden, (long)N, (long)K, Xout);
-            DCP_LAUNCH_OK(h, hipGetLastError());
+            if (split_gram) {
+                GemmArgs<T> q;   // x_new = x * max(sum slabs, 0) / max(x G, eps)
+                q.A = Xin; q.lda = K; q.B = w.G; q.ldb = K; q.M = N; q.N = K; q.K = K;
+                DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, q, EpiMuDenSlabs<T>{Xin, K, w.slabs, K, (long)N * K,
+                                                                        pg.ksplits, Xout, K})));
+            } else {
+                hipLaunchKernelGGL((mu_quotient_slabs_kernel<T>), dim3(grid_for((long)N * K)), dim3(256),
+                                   0, st, Xin, (const T*)w.slabs, (long)N * K, pg.ksplits, xden,
+                                   (long)ld_xden, (long)N, (long)K, Xout);
+                DCP_LAUNCH_OK(h, hipGetLastError());
+            }
         }
     }
     X = Xout;

@@ -94,6 +94,13 @@ def test_c4_shard_oracle_parity_masked():
     assert max(ddiff) <= 1e-5, ddiff
 
 
+def test_c2_shard_oracle_parity():
+    """One 8192-row shard of configs[1]: the split Y.D^T product with the quotient in the x.G epilogue."""
+    rel, ddiff = _oracle_vs_hip(8192, seed=29, masked=False)
+    assert max(rel) <= 1e-5, rel
+    assert max(ddiff) <= 1e-5, ddiff
+
+
 def test_c2_properties():
     import torch
     import decomp_amd
