@@ -159,8 +159,14 @@ inline size_t dict_slab_elems(int64_t Nb, int64_t F, int64_t K) {
     GemmArgs<T> a;
     a.M = (int)K; a.N = (int)(F + K); a.K = (int)Nb;
     a.B2 = reinterpret_cast<const T*>(1); a.n_b1 = (int)F;   // two segments (tile count only)
+    a.conjA = true;                                          // as dict_local_stats plans it
     plan_splits<FORM_TN>(a, kSplitTarget, kMaxSplits);
-    return (size_t)a.ksplits * K * (F + K);
+    GemmArgs<T> b;   // the masked variant's x^H (y o m) alone (dict_api.hpp): its own plan
+    b.M = (int)K; b.N = (int)F; b.K = (int)Nb;
+    b.conjA = true;
+    plan_splits<FORM_TN>(b, kSplitTarget, kMaxSplits);
+    const size_t both = (size_t)a.ksplits * K * (F + K), single = (size_t)b.ksplits * K * F;
+    return both > single ? both : single;
 }
 
 // stats[K, F+K] = X^H [Y | X] for this rank's rows of the minibatch

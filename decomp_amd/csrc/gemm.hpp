@@ -64,6 +64,23 @@ __global__ void __launch_bounds__(256) cplx_ext_kernel(const cx<R>* __restrict__
     }
 }
 
+// Planar rows of a complex [R, C] matrix: real [2R, C], row 2r = Re A[r, :], row 2r+1 = Im A[r, :].
+// With it a product A B whose LEFT operand is the small one needs no image of B at all:
+//   NN, C = A B : G = rows(A) . B_real (B's own memory as [K, 2N]); the 2x2 block (rr ri; ir ii) of G gives
+//   re = rr - ii, im = ri + ir in the epilogue (mode 3)
+// (atom-block products [32 x K].[K x F]: the image of the F-long operand was 2/3 of their time).
+template <class R>
+__global__ void __launch_bounds__(256) cplx_rows_kernel(const cx<R>* __restrict__ A, long rows, long cols,
+                                                        long ld, R* __restrict__ out) {
+    const long n = rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const long r = i / cols, c = i - r * cols;
+        const cx<R> v = A[r * ld + c];
+        out[(2 * r) * cols + c] = v.re;
+        out[(2 * r + 1) * cols + c] = v.im;
+    }
+}
+
 template <class E, class R = float>
 struct CplxColEpi {   // kernel epilogue mode 1
     static constexpr int kMode = 1;
@@ -82,6 +99,22 @@ struct CplxTnEpi {    // kernel epilogue mode 2
     }
     __device__ __forceinline__ void operator()(int, int, R, int) const {}
 };
+
+template <class E, class R = float>
+struct CplxNnEpi {    // kernel epilogue mode 3
+    static constexpr int kMode = 3;
+    E e;
+    __device__ __forceinline__ void pair(int r, int c, R re, R im, int s) const {
+        e(r, c, cx<R>{re, im}, s);
+    }
+    __device__ __forceinline__ void operator()(int, int, R, int) const {}
+};
+
+// complex64 NN products whose left operand is the smaller one take the planar-rows form
+template <int FORM>
+inline bool cplx_planar_a(int M, int N, bool conjA, bool conjB, const void* ext_ws) {
+    return FORM == FORM_NN && !conjA && !conjB && ext_ws != nullptr && M < N;
+}
 
 template <int FORM>
 inline bool cplx_on_mfma(bool conjA, bool conjB, const void* ext_ws) {
@@ -160,7 +193,8 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_b
     if (std::is_same<T, c64>::value && cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws)) {
         mfma = true;
         Nx *= 2; n1 *= 2;
-        if (FORM == FORM_TN) Mx *= 2; else Kx *= 2;
+        if (FORM == FORM_TN || cplx_planar_a<FORM>(a.M, a.N, a.conjA, a.conjB, a.ext_ws)) Mx *= 2;
+        else Kx *= 2;
     }
     if (mfma) tier_dims(pick_tier<FORM>(Mx, Nx, Kx, a.tile, true), bm, bn);
     if (std::is_same<T, double>::value && f64_on_mfma(a.M, a.N, a.tile)) { bm = F64Tile::BM; bn = F64Tile::BN; }
@@ -182,9 +216,49 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_b
     long s = tiles > 0 ? target_wgs / tiles : 1;  // floor: stay within `target` resident slots
     if (s > smax) s = smax;
     if (s < 1) s = 1;
+    if (FORM == FORM_TN && mfma && bm == CfgLarge::BM && s == 1 && tiles > target_wgs) {
+        // A grid just over a whole number of rounds of resident 128x128 workgroups (complex64 minibatch
+        // statistics: 1088 tiles on 1024 slots) leaves the chip nearly empty for a whole tile's time: shorter
+        // workgroups shrink that tail.  Cost model: rounds / s + 1.5 % per extra set of partial slabs; every
+        // split at least 1024 deep.  Measured 1024 x 17408 x 8192: 1 split 2.63 ms, 2: 2.42, 3: 2.32, 4: 2.29, 5: 2.40.
+        double best = 1e30;
+        long best_s = 1;
+        for (long c = 1; c <= 4 && c <= kblocks / 64 && c <= max_splits; ++c) {
+            const double rounds = (double)((tiles * c + target_wgs - 1) / target_wgs);
+            const double cost = rounds / (double)c + 0.015 * (double)c;
+            if (cost < best - 1e-9) { best = cost; best_s = c; }
+        }
+        s = best_s;
+    }
     const long blocks_per_split = (kblocks + s - 1) / s;
     a.klen = (int)(blocks_per_split * 16);   // in units of the core's reduction index (see gemm())
     a.ksplits = ceil_div(Kx > 0 ? Kx : 1, a.klen);
+    return a.ksplits;
+}
+
+// A . B^H with a deep reduction whose 256x256 tiles alone cannot fill the chip (complex64 minibatch y.A^H:
+// 8192 x 1024 x 16384 as the real core sees it -> 128 tiles): S splits on the big tile instead of the un-split
+// 128x128 tile (measured 2.27 -> 1.99 ms including the ordered slab sum).  Every split stays >= 8192 deep: at
+// 4096 (float32 minibatch, 64 tiles) the two plans tie.  Returns S and plans `a` for it; 1 leaves `a` untouched.
+template <class T>
+inline int plan_deep_nt(GemmArgs<T>& a, int max_s) {
+    long Mx = a.M, Nx = a.N, Kx = a.K;
+    if (std::is_same<T, c64>::value) {
+        if (!cplx_on_mfma<FORM_NT>(a.conjA, a.conjB, a.ext_ws)) return 1;
+        Nx *= 2; Kx *= 2;
+    } else if (!std::is_same<T, float>::value) {
+        return 1;
+    }
+    if (Mx < CfgHuge::BM || Nx < CfgHuge::BN) return 1;
+    const long wh = (long)ceil_div(Mx, CfgHuge::BM) * ceil_div(Nx, CfgHuge::BN);
+    if (wh >= 192) return 1;
+    const long S = (256 + wh - 1) / wh;
+    if (S < 2 || S > max_s || Kx / S < 8192) return 1;
+    const long kblocks = (Kx + 15) / 16;
+    a.tile = TILE_HUGE;
+    a.klen = (int)(((kblocks + S - 1) / S) * 16);
+    a.ksplits = ceil_div(Kx, a.klen);
+    a.split_planned = true;
     return a.ksplits;
 }
 
@@ -232,6 +306,22 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     CplxTnEpi<Epi> ce{epi};
                     const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
                     if (tier == TIER_SMALL || tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
+                    return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
+                } else if (cplx_planar_a<FORM>(a.M, a.N, a.conjA, a.conjB, a.ext_ws)) {
+                    // rows(A): [2M, K] real image in the caller's scratch (2MK <= 4KN reals); B as it lies
+                    long g = ((long)a.M * a.K + 255) / 256;
+                    if (g > 4096) g = 4096;
+                    if (g < 1) g = 1;
+                    hipLaunchKernelGGL((cplx_rows_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, a.A,
+                                       (long)a.M, (long)a.K, a.lda, a.ext_ws);
+                    p.A = a.ext_ws; p.lda = a.K;
+                    p.B = reinterpret_cast<const float*>(a.B); p.ldb = 2 * a.ldb;
+                    p.M = 2 * a.M; p.N = 2 * a.N; p.K = a.K;
+                    if (a.ksplits <= 1) p.klen = 0;
+                    CplxNnEpi<Epi> ce{epi};
+                    const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
+                    if (tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmallDeep, AL, BL>(stream, p, ce);
+                    if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
                 } else {
                     // ext(B): [2 rows(B), 2 cols(B)] real image in the caller's scratch

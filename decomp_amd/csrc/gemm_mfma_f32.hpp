@@ -585,6 +585,8 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     //   2  complex x^H y on the real views of both operands: the 2x2 block of real sums
     //      (rr ri; ir ii) sits in registers r, r+1 of lanes 2q, 2q+1:
     //      re = rr + ii, im = ri - ir  (two shuffles), even lanes call the complex functor
+    //   3  complex x y with the planar rows of x against the real view of y: the same 2x2 block,
+    //      re = rr - ii, im = ri + ir
     constexpr int MODE = epi_mode<Epi>::value;
     if constexpr (MODE == 0 && !EDGE && !ROWBITS && epi_vec4<Epi>::value) {
         if (p.vec_epi) {
@@ -636,7 +638,9 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
                     const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
                     const float p1 = __shfl_xor(v1, 1, 64);
-                    const float comb = (lane & 1) ? (v0 - p1) : (v0 + p1);   // odd: ri - ir, even: rr + ii
+                    // mode 2  odd: ri - ir, even: rr + ii ;  mode 3  odd: ri + ir, even: rr - ii
+                    const bool plus = (MODE == 2) ? !(lane & 1) : (lane & 1);
+                    const float comb = plus ? (v0 + p1) : (v0 - p1);
                     const float other = __shfl_xor(comb, 1, 64);
                     if (!(lane & 1) && (!EDGE || (row < p.M && col < ncol_end)))
                         epi.pair(row >> 1, col >> 1, comb, other, split);

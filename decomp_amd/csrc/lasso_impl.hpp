@@ -613,7 +613,17 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         GemmArgs<T> a;
         a.A = Yuse; a.lda = F; a.B = w.An; a.ldb = F; a.M = N; a.N = K; a.K = F; a.conjB = true;
         a.ext_ws = w.ext1;
-        DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a, EpiStore<T>{w.yAt, K})));
+        // deep reduction, few big tiles: ordered split-K partials in the (still unused) iterate buffers
+        const long stride = (long)(w.xb[2] - w.xb[1]);
+        const int ys = (stride >= (long)N * K && w.xb[3] - w.xb[2] == stride) ? plan_deep_nt(a, 3) : 1;
+        if (ys > 1) {
+            DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a, EpiSlab<T>{w.xb[1], K, stride})));
+            hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st,
+                               (const T*)w.xb[1], stride, ys, (long)N * K, w.yAt);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+        } else {
+            DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a, EpiStore<T>{w.yAt, K})));
+        }
     }
     const R* rowscale = mask_ndim == 2 ? w.rowscale : nullptr;
     int it = maxiter - 1;

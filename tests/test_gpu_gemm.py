@@ -116,7 +116,9 @@ def test_c64_on_mfma(form):
     (form 0: A B^H, 1: A B, 2: A^H B); aligned, ragged and split-K shapes."""
     rng = np.random.RandomState(40 + form)
     for (M, N, K, ks) in [(256, 256, 128, 1), (128, 64, 512, 4), (101, 20, 3, 1), (37, 65, 129, 3),
-                          (512, 128, 256, 1), (64, 96, 1000, 7), (5, 3, 10, 1)]:
+                          (512, 128, 256, 1), (64, 96, 1000, 7), (5, 3, 10, 1),
+                          # left operand the smaller one: A B takes the planar-rows form (no image of B)
+                          (32, 1024, 512, 1), (31, 333, 130, 1), (64, 2048, 64, 1), (16, 512, 2048, 4)]:
         if form == 0:
             A, B = _cplx(rng, M, K), _cplx(rng, N, K)
             ref = A.astype(np.complex128) @ B.astype(np.complex128).conj().T
