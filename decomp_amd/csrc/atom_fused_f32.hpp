@@ -185,7 +185,7 @@ inline int atom_sweep_fused_f32(dcp_handle* h, const float* A, const float* B, f
     const int nblk = K / 64, ntile = F / 64;
     if ((size_t)ntile * 64 * 64 > w.slab_count) return fail(h, DCP_ERR_INTERNAL, "atom slab plan");
     hipLaunchKernelGGL((atom_prep_kernel<float>), dim3(grid_for((long)K * K, 256)), dim3(256), 0, st, 64, K, A,
-                       w.Ablk, w.Wl, w.rden, w.Alook, w.Aprev);
+                       w.Ablk, w.Wl, w.rden, w.Alook, w.Aprev, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     DCP_LAUNCH_OK(h, hipGetLastError());
     {
         static DynLdsRaised raised;

@@ -64,9 +64,13 @@ template <class T>
 __global__ void __launch_bounds__(256) atom_prep_kernel(int blk, int K, const T* __restrict__ A,
                                                         T* __restrict__ Ablk, T* __restrict__ Wl,
                                                         T* __restrict__ rden, T* __restrict__ Alook,
-                                                        T* __restrict__ Aprev) {
+                                                        T* __restrict__ Aprev, real_t<T>* __restrict__ rows_blk,
+                                                        real_t<T>* __restrict__ rows_look,
+                                                        real_t<T>* __restrict__ rows_prev) {
     typedef typename wide_of<T>::type WT;
     typedef real_t<WT> WR;
+    // rows_*: planar-rows images of the same matrices (row 2r = Re, row 2r+1 = Im), complex64 only: the left
+    // operands of the sweep's A.B products as the MFMA core takes them (gemm.hpp, cplx_rows_kernel)
     for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)K * K; e += (long)gridDim.x * 256L) {
         const int r = (int)(e / K), j = (int)(e % K);
         const int k0 = (r / blk) * blk;
@@ -74,8 +78,12 @@ __global__ void __launch_bounds__(256) atom_prep_kernel(int blk, int K, const T*
         const int jl = j - k0;
         if (jl >= 0 && jl < r - k0) v = zero_of<T>();
         Ablk[e] = v;
+        if constexpr (scalar_traits<T>::is_complex)
+            if (rows_blk) { rows_blk[(2L * r) * K + j] = v.re; rows_blk[(2L * r + 1) * K + j] = v.im; }
         if (jl < 0 && jl >= -blk) v = zero_of<T>();
         Alook[e] = v;
+        if constexpr (scalar_traits<T>::is_complex)
+            if (rows_look) { rows_look[(2L * r) * K + j] = v.re; rows_look[(2L * r + 1) * K + j] = v.im; }
     }
     for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)K * kAtomBlkMax; e += (long)gridDim.x * 256L) {
         const int r = (int)(e / kAtomBlkMax), j = (int)(e % kAtomBlkMax);
@@ -87,6 +95,11 @@ __global__ void __launch_bounds__(256) atom_prep_kernel(int blk, int K, const T*
             v = narrow<T>(mul(widen(A[(long)r * K + (k0 - blk + j)]), scale(rd, WR(-1))));
         }
         Aprev[e] = v;
+        if constexpr (scalar_traits<T>::is_complex)
+            if (rows_prev) {
+                rows_prev[(2L * r) * kAtomBlkMax + j] = v.re;
+                rows_prev[(2L * r + 1) * kAtomBlkMax + j] = v.im;
+            }
     }
     for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)K * kAtomBlkMax; e += (long)gridDim.x * 256L) {
         const int r = (int)(e / kAtomBlkMax), j = (int)(e % kAtomBlkMax);
@@ -164,7 +177,8 @@ constexpr int kAtomSub = 8;
 
 template <class T>
 __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int nb, const T* __restrict__ G,
-                                                const T* __restrict__ Wl, T* __restrict__ E) {
+                                                const T* __restrict__ Wl, T* __restrict__ E,
+                                                real_t<T>* __restrict__ E_rows = nullptr) {
     typedef typename wide_of<T>::type WT;
     typedef real_t<WT> WR;
     constexpr int BMAX = atom_blk<T>();
@@ -227,7 +241,15 @@ __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int
                         sE[k][i] = e;
                         sM[k][i] = m;
                     }
-                    if (live) E[(long)k * nb + i] = narrow<T>(e);
+                    if (live) {
+                        const T en = narrow<T>(e);
+                        E[(long)k * nb + i] = en;
+                        if constexpr (scalar_traits<T>::is_complex)
+                            if (E_rows) {   // planar rows of E for the E.P product
+                                E_rows[(2L * k) * nb + i] = en.re;
+                                E_rows[(2L * k + 1) * nb + i] = en.im;
+                            }
+                    }
                 }
             }
         }
@@ -254,9 +276,10 @@ __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int
 
 template <class T>
 __global__ void __launch_bounds__(256) atom_recur_kernel(int nb, const T* __restrict__ G,
-                                                         const T* __restrict__ Wl, T* __restrict__ E) {
+                                                         const T* __restrict__ Wl, T* __restrict__ E,
+                                                         real_t<T>* __restrict__ E_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char atom_lds_dyn[];
-    atom_recur_body<T>(atom_lds_dyn, nb, G, Wl, E);
+    atom_recur_body<T>(atom_lds_dyn, nb, G, Wl, E, E_rows);
 }
 
 template <class T>
@@ -277,6 +300,11 @@ struct AtomWs {
     T* slabs = nullptr;  // split-K partials of G
     size_t slab_count = 0;
     real_t<T>* ext = nullptr;   // complex: real extended images (max(4KF, 4*64*F) reals)
+    // complex64: planar-rows images of Ablk, Alook [2K, K], Aprev [2K, 64] and E [128, 64]
+    real_t<T>* rows_blk = nullptr;
+    real_t<T>* rows_look = nullptr;
+    real_t<T>* rows_prev = nullptr;
+    real_t<T>* rows_E = nullptr;
 };
 
 // Gram slabs: up to 64 split-K slabs of the generic path, or one per 64-column tile of the fused float path
@@ -297,6 +325,12 @@ inline void atom_plan(WsPlan& p, int64_t F, int64_t K) {
     p.add<T>((size_t)K);
     p.add<T>(atom_slab_elems(F));
     if (scalar_traits<T>::is_complex) p.add<real_t<T> >((size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
+    if (std::is_same<T, c64>::value) {
+        p.add<real_t<T> >((size_t)2 * K * K);
+        p.add<real_t<T> >((size_t)2 * K * K);
+        p.add<real_t<T> >((size_t)2 * K * kAtomBlkMax);
+        p.add<real_t<T> >((size_t)2 * kAtomBlkMax * kAtomBlkMax);
+    }
 }
 
 template <class T>
@@ -314,6 +348,14 @@ inline int atom_carve(dcp_handle* h, AtomWs<T>& w, int64_t F, int64_t K) {
     if (scalar_traits<T>::is_complex) {
         w.ext = ws_alloc<real_t<T> >(h, (size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
         if (!w.ext) return fail(h, DCP_ERR_INTERNAL, "atom sweep workspace plan");
+    }
+    if (std::is_same<T, c64>::value) {
+        w.rows_blk = ws_alloc<real_t<T> >(h, (size_t)2 * K * K);
+        w.rows_look = ws_alloc<real_t<T> >(h, (size_t)2 * K * K);
+        w.rows_prev = ws_alloc<real_t<T> >(h, (size_t)2 * K * kAtomBlkMax);
+        w.rows_E = ws_alloc<real_t<T> >(h, (size_t)2 * kAtomBlkMax * kAtomBlkMax);
+        if (!w.rows_blk || !w.rows_look || !w.rows_prev || !w.rows_E)
+            return fail(h, DCP_ERR_INTERNAL, "atom sweep workspace plan");
     }
     if (!w.Ablk || !w.Alook || !w.Aprev || !w.P || !w.G || !w.E || !w.Wl || !w.rden || !w.slabs)
         return fail(h, DCP_ERR_INTERNAL, "atom sweep workspace plan");
@@ -338,7 +380,7 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
     const int K = (int)K64, F = (int)F64;
     constexpr int BLK = atom_blk<T>();
     hipLaunchKernelGGL((atom_prep_kernel<T>), dim3(grid_for((long)K * K, 256)), dim3(256), 0, st, BLK, K, A,
-                       w.Ablk, w.Wl, w.rden, w.Alook, w.Aprev);
+                       w.Ablk, w.Wl, w.rden, w.Alook, w.Aprev, w.rows_blk, w.rows_look, w.rows_prev);
     DCP_LAUNCH_OK(h, hipGetLastError());
     {
         static DynLdsRaised raised;   // per dtype
@@ -358,9 +400,10 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
     // it; once D_new[block b] is there, its contribution is a 64-deep product added in place.
     const int nblk = (K + BLK - 1) / BLK;
     const bool lookahead = nblk > 1;
-    auto p_product = [&](hipStream_t s_, const T* Arows, int k0, int nb, T* Pout) -> int {
+    auto p_product = [&](hipStream_t s_, const T* Arows, const real_t<T>* Aplanar, int k0, int nb, T* Pout) -> int {
         GemmArgs<T> a;   // P = (B_blk - Arows . D_cur) * rden + D_old[blk]
         a.A = Arows + (long)k0 * K; a.lda = K; a.B = Dnew; a.ldb = F; a.M = nb; a.N = F; a.K = K;
+        if (Aplanar) { a.A_rows = Aplanar + 2L * k0 * K; a.lda_rows = K; }
         a.tile = TILE_SMALL_DEEP;
         a.ext_ws = w.ext;
         DCP_LAUNCH_OK(h, (gemm<FORM_NN>(s_, a, EpiAtomP<T>{B + (long)k0 * F, Dnew + (long)k0 * F, w.rden + k0,
@@ -369,7 +412,7 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
     };
     {   // block 0: nothing to wait for
         const int nb0 = K < BLK ? K : BLK;
-        DCP_TRY(p_product(st, w.Ablk, 0, nb0, w.P));
+        DCP_TRY(p_product(st, w.Ablk, w.rows_blk, 0, nb0, w.P));
     }
     for (int b = 0; b < nblk; ++b) {
         const int k0 = b * BLK;
@@ -397,16 +440,17 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
             // (blocks < b are final in D_new; the complex path's ext scratch is free again) and reads
             // block b's OLD rows only through zero weights.
             DCP_TRY(side_after_main(h));
-            DCP_TRY(p_product(h->side, w.Alook, k1, nb1, Pnext));
+            DCP_TRY(p_product(h->side, w.Alook, w.rows_look, k1, nb1, Pnext));
         }
         // (3) the b-step recursion in coefficient space
         hipLaunchKernelGGL((atom_recur_kernel<T>), dim3(1), dim3(256), atom_recur_lds_bytes<T>(), st, nb,
-                           (const T*)w.G, (const T*)(w.Wl + (long)k0 * kAtomBlkMax), w.E);
+                           (const T*)w.G, (const T*)(w.Wl + (long)k0 * kAtomBlkMax), w.E, w.rows_E);
         DCP_LAUNCH_OK(h, hipGetLastError());
         if (has_next && lookahead) DCP_TRY(main_after_side(h));   // (also frees the ext scratch for (4))
         {   // (4) D_new[blk] = E . P
             GemmArgs<T> a;
             a.A = w.E; a.lda = nb; a.B = P; a.ldb = F; a.M = nb; a.N = F; a.K = nb;
+            a.A_rows = w.rows_E; a.lda_rows = nb;
             a.tile = TILE_SMALL_DEEP;
             a.ext_ws = w.ext;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiStore<T>{Dnew + (long)k0 * F, (long)F})));
@@ -415,6 +459,7 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
             GemmArgs<T> a;
             a.A = w.Aprev + (long)k1 * kAtomBlkMax; a.lda = kAtomBlkMax; a.B = Dnew + (long)k0 * F; a.ldb = F;
             a.M = nb1; a.N = F; a.K = nb;
+            if (w.rows_prev) { a.A_rows = w.rows_prev + 2L * k1 * kAtomBlkMax; a.lda_rows = kAtomBlkMax; }
             a.tile = TILE_SMALL_DEEP;
             a.ext_ws = w.ext;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiAddTo<T>{Pnext, (long)F})));

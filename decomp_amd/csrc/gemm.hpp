@@ -40,6 +40,10 @@ struct GemmArgs {
     // complex only: scratch for the real "extended" image of B (4 * rows(B) * cols(B) reals).
     // With it NT / NN products run on the fp32 / fp64 MFMA core; TN needs none.  Null -> generic core.
     real_t<T>* ext_ws = nullptr;
+    // complex64 NN only: the planar-rows image of A ([2M, K] reals, leading dim lda_rows) when the caller
+    // already holds it (the atom sweep prepares its block matrices that way once per sweep)
+    const real_t<T>* A_rows = nullptr;
+    long lda_rows = 0;
 };
 
 // complex64 products on the fp32 MFMA core --------------------------------------------------
@@ -309,12 +313,16 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
                 } else if (cplx_planar_a<FORM>(a.M, a.N, a.conjA, a.conjB, a.ext_ws)) {
                     // rows(A): [2M, K] real image in the caller's scratch (2MK <= 4KN reals); B as it lies
-                    long g = ((long)a.M * a.K + 255) / 256;
-                    if (g > 4096) g = 4096;
-                    if (g < 1) g = 1;
-                    hipLaunchKernelGGL((cplx_rows_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, a.A,
-                                       (long)a.M, (long)a.K, a.lda, a.ext_ws);
-                    p.A = a.ext_ws; p.lda = a.K;
+                    if (a.A_rows != nullptr) {
+                        p.A = a.A_rows; p.lda = a.lda_rows;
+                    } else {
+                        long g = ((long)a.M * a.K + 255) / 256;
+                        if (g > 4096) g = 4096;
+                        if (g < 1) g = 1;
+                        hipLaunchKernelGGL((cplx_rows_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, a.A,
+                                           (long)a.M, (long)a.K, a.lda, a.ext_ws);
+                        p.A = a.ext_ws; p.lda = a.K;
+                    }
                     p.B = reinterpret_cast<const float*>(a.B); p.ldb = 2 * a.ldb;
                     p.M = 2 * a.M; p.N = 2 * a.N; p.K = a.K;
                     if (a.ksplits <= 1) p.klen = 0;
