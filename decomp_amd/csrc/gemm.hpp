@@ -85,14 +85,33 @@ __global__ void __launch_bounds__(256) cplx_rows_kernel(const cx<R>* __restrict_
     }
 }
 
+// A complex64 functor may carry `static constexpr bool kCVec2 = true` with
+//     bool cvec_ok() const                                   (host: arrays 16-byte aligned, leading dims even)
+//     void cvec2(int row, int col0, f32x4 v, int split) const   (v = re, im of columns col0 and col0 + 1)
+// In mode 1 the real accumulator columns 2n / 2n+1 ARE (re, im), so the core's 16-byte epilogue (epi_vec4)
+// hands a lane two complex outputs of one row: all lanes active, 16 bytes per load / store, instead of
+// 8 bytes on the even lanes.
+template <class E, class = void>
+struct epi_cvec2 { static constexpr bool value = false; };
+template <class E>
+struct epi_cvec2<E, decltype((void)E::kCVec2)> { static constexpr bool value = E::kCVec2; };
+
 template <class E, class R = float>
 struct CplxColEpi {   // kernel epilogue mode 1
     static constexpr int kMode = 1;
+    static constexpr bool kVec4 = std::is_same<R, float>::value && epi_cvec2<E>::value;
     E e;
     __device__ __forceinline__ void pair(int r, int c, R re, R im, int s) const {
         e(r, c, cx<R>{re, im}, s);
     }
     __device__ __forceinline__ void operator()(int, int, R, int) const {}
+    bool vec_ok() const {
+        if constexpr (kVec4) return e.cvec_ok();
+        else return false;
+    }
+    __device__ __forceinline__ void vec4(int r, int c0, f32x4 v, int s) const {
+        if constexpr (kVec4) e.cvec2(r, c0 >> 1, v, s);
+    }
 };
 template <class E, class R = float>
 struct CplxTnEpi {    // kernel epilogue mode 2

@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     //   3  complex x y with the planar rows of x against the real view of y: the same 2x2 block,
     //      re = rr - ii, im = ri + ir
     constexpr int MODE = epi_mode<Epi>::value;
-    if constexpr (MODE == 0 && !EDGE && !ROWBITS && epi_vec4<Epi>::value) {
+    if constexpr ((MODE == 0 || MODE == 1) && !EDGE && !ROWBITS && epi_vec4<Epi>::value) {
         if (p.vec_epi) {
             const int t = l31 & 3, col0 = (l31 & ~3);
 #pragma unroll

@@ -120,6 +120,40 @@ struct EpiProxStep {
             if (viol) *flag = 1;
         }
     }
+    // complex64: two consecutive columns of a row (16 bytes) per call, see CplxColEpi
+    static constexpr bool kCVec2 = std::is_same<T, c64>::value;
+    bool cvec_ok() const {
+        return al16_ptr(yAt) && al16_ptr(v) && al16_ptr(xprev) && al16_ptr(xnew) &&
+               (vnext == nullptr || al16_ptr(vnext)) && (ld % 2) == 0;
+    }
+    __device__ __forceinline__ void cvec2(int r, int c0, f32x4 back, int) const {
+        if constexpr (std::is_same<T, c64>::value) {
+            const long i = (long)r * ld + c0;
+            const float li = Linv[0];
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(yAt + i);
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(v + i);
+            const f32x4 p4 = *reinterpret_cast<const f32x4*>(xprev + i);
+            const float rs = rowscale != nullptr ? rowscale[r] : 1.0f;
+            f32x4 xn4, vn4;
+            bool viol = false;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const c64 bk{back[2 * e], back[2 * e + 1]};
+                const c64 z = add(c64{v4[2 * e], v4[2 * e + 1]}, scale(sub(c64{y4[2 * e], y4[2 * e + 1]}, bk), li));
+                float thr = li * alpha[c0 + e];
+                if (rowscale != nullptr) thr = li * (alpha[c0 + e] * rs);
+                const c64 xn = prox_apply<PROX>(z, thr);
+                const c64 d = sub(xn, c64{p4[2 * e], p4[2 * e + 1]});
+                const c64 vn = add(xn, scale(d, coef));
+                xn4[2 * e] = xn.re; xn4[2 * e + 1] = xn.im;
+                vn4[2 * e] = vn.re; vn4[2 * e + 1] = vn.im;
+                if (check && !((absval(d) - tolk[c0 + e]) < 0.0f)) viol = true;
+            }
+            *reinterpret_cast<f32x4*>(xnew + i) = xn4;
+            if (vnext != nullptr) *reinterpret_cast<f32x4*>(vnext + i) = vn4;
+            if (viol) *flag = 1;
+        }
+    }
 };
 
 // out = base - acc   (g = yAt - x.AAt for coordinate descent)
