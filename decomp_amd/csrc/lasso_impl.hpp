@@ -300,15 +300,20 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
     const int M = (K + 63) / 64;
     T x[MAXM], g[MAXM], akk[MAXM];
     R al[MAXM], tl[MAXM];
+    // (loads are unconditional on a clamped column and selected afterwards: a load under a lane
+    //  predicate becomes its own branch + full wait, i.e. one memory round trip per slot)
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) {
         const int c = lane + 64 * m;
         const bool ok = (m < M && c < K);
-        x[m] = ok ? X[row * K + c] : zero_of<T>();
-        g[m] = ok ? G[row * K + c] : zero_of<T>();
-        akk[m] = ok ? AAt[(long)c * K + c] : zero_of<T>();
-        al[m] = ok ? alphak[c] : R(0);
-        tl[m] = ok ? tolk[c] : R(1);
+        const int cc = ok ? c : 0;
+        const T xv = X[row * K + cc], gv = G[row * K + cc], av = AAt[(long)cc * K + cc];
+        const R alv = alphak[cc], tlv = tolk[cc];
+        x[m] = ok ? xv : zero_of<T>();
+        g[m] = ok ? gv : zero_of<T>();
+        akk[m] = ok ? av : zero_of<T>();
+        al[m] = ok ? alv : R(0);
+        tl[m] = ok ? tlv : R(1);
     }
     bool viol = false;
     for (int s = 0; s < nsweeps; ++s) {
@@ -344,10 +349,17 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
                     if (check && !((absval(d) - tl[m]) < R(0))) viol = true;
                 }
                 const T* arow = AAt + (long)(64 * m + kk) * K;
+                T ar[MAXM];   // the whole row in flight at once (one L2 round trip per applied step)
 #pragma unroll
                 for (int mm = 0; mm < MAXM; ++mm) {
                     const int c = lane + 64 * mm;
-                    if (mm < M && c < K) g[mm] = sub(g[mm], mul(dk, arow[c]));
+                    ar[mm] = arow[(mm < M && c < K) ? c : 0];
+                }
+#pragma unroll
+                for (int mm = 0; mm < MAXM; ++mm) {
+                    const int c = lane + 64 * mm;
+                    const T gn = sub(g[mm], mul(dk, ar[mm]));
+                    g[mm] = (mm < M && c < K) ? gn : g[mm];
                 }
                 cursor = kk + 1;
             }
