@@ -222,16 +222,20 @@ def secondary_configs(torch, device):
     md, lit = ctypes.c_double(0), ctypes.c_int(0)
     state = {'D': D, 'Dn': D_new, 'count': 0}
 
-    def dl_step():
+    def dl_step(method=_hip.LASSO_ISTA):
         theta = state['count'] * MB + 1.0
         _hip.check(h, lib.dcp_dict_step_f32(h, _arrays.ptr(Y), _arrays.ptr(x), _arrays.ptr(state['D']),
                                             _arrays.ptr(state['Dn']), _arrays.ptr(A), _arrays.ptr(B), MB, F, K,
-                                            (theta - MB) / theta, 0.1, _hip.LASSO_ISTA, 10, 1e-5,
+                                            (theta - MB) / theta, 0.1, method, 10, 1e-5,
                                             ctypes.byref(md), ctypes.byref(lit)), 'dict_step')
         state['D'], state['Dn'] = state['Dn'], state['D']
         state['count'] += 1
     out['dictionary_step_ms'] = {'workload': 'configs[2] minibatch 8192x4096 k=512 ista x10 fp32',
                                  'value': round(ms_of(dl_step, 6), 4)}
+    # the same step with the reference's DEFAULT inner solver (dictionary_learning.py:14, lasso_method='cd'),
+    # codes carried over from the previous visit of the minibatch as in the reference's epochs
+    out['dictionary_step_cd_ms'] = {'workload': "configs[2] minibatch 8192x4096 k=512 cd x10 fp32",
+                                    'value': round(ms_of(lambda: dl_step(_hip.LASSO_CD), 6), 4)}
     del Y, x, A, B, D, D_new, Dt, xt
 
     # configs[3]: masked NMF MU, one GPU's shard 16384 x 4096, k = 256, 20 % missing, fp32
