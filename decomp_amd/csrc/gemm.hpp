@@ -299,7 +299,15 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
         constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
         constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
-        const int tier = pick_tier<FORM>(a.M, a.N, a.K, a.tile, a.split_planned);
+        int tier = pick_tier<FORM>(a.M, a.N, a.K, a.tile, a.split_planned);
+        if (tier == TIER_SMALL && a.tile == TILE_AUTO) {
+            // at most one workgroup per CU: occupancy is moot and the product is a chain of
+            // load -> LDS -> MFMA round trips, one per K block; 64-deep blocks make 4x fewer of them
+            // (small problems: Y.D^T 2048 x 32 x 512 31 -> 10 us).  Same summation order.
+            const long wgs = (long)ceil_div(a.M, 64) * ceil_div(a.N, 64) * (a.ksplits > 1 ? a.ksplits : 1);
+            const int depth = a.ksplits > 1 ? a.klen : a.K;
+            if (wgs <= 256 && depth >= 256 && depth % 64 == 0 && a.K % 64 == 0) tier = TIER_SMALL_DEEP;
+        }
         if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL, Epi>(stream, p, epi);
         if (tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmallDeep, AL, BL, Epi>(stream, p, epi);
         if constexpr (FORM != FORM_TN) {
