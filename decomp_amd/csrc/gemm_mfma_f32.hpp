@@ -61,6 +61,7 @@ struct GemmProblem {
     int tiles_m1;  // m tiles that belong to the first A segment
     int mt_fast;   // 1: consecutive logical ids walk m tiles first
     int vec_epi;   // set by the launcher: the functor's 16-byte epilogue (vec4) may be used
+    int al_mask;   // set by the launcher: bit 0 / 1 / 2 / 3 = A / A2 / B / B2 is 16-byte aligned with ld % 4 == 0
 };
 
 // PIPE_ = 1: the per-block barrier sits between the MFMA groups of a K block (operands of the
@@ -172,36 +173,54 @@ struct PanelGeom {
     static_assert(ROWS * BK % (4 * NT) == 0, "panel must be a whole number of float4 per thread");
 };
 
-// Loads one panel block into registers.  EDGE: scalar, predicated, any alignment.
+// Loads one panel block into registers.
+// EDGE (ragged / unaligned problems): `vec` (wave-uniform) says that this operand is 16-byte aligned, the
+// whole K block lies inside the reduction range and -- for row-contiguous panels -- the whole tile lies
+// inside the matrix: then the load is the fast path's 16-byte load with the ROW index clamped (rows past
+// the end fetch a duplicate; they only feed accumulator rows / columns the epilogue never stores).
+// Otherwise every element is fetched on its own from a clamped address and zeroed by a select: no load
+// sits under a lane predicate (a predicated load compiles to a branch and a full wait of its own).
 template <int LAY, int ROWS, int BK, bool EDGE, int NT, int F4>
 __device__ __forceinline__ void panel_gload(f32x4 (&r)[F4],
                                             const float* __restrict__ p, long ld, int row0,
-                                            int nrows, int k0, int kend, int tid) {
+                                            int nrows, int k0, int kend, int tid, bool vec = false) {
     static_assert(F4 == PanelGeom<LAY, ROWS, BK, NT>::F4, "register panel size");
 #pragma unroll
     for (int i = 0; i < F4; ++i) {
         const int idx = tid + i * NT;
         if (LAY == KMAJOR) {
             const int row = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
-            const float* src = p + (long)(row0 + row) * ld + (k0 + kq);
             if (!EDGE) {
-                r[i] = *reinterpret_cast<const f32x4*>(src);
+                r[i] = *reinterpret_cast<const f32x4*>(p + (long)(row0 + row) * ld + (k0 + kq));
             } else {
                 const bool rok = (row0 + row) < nrows;
+                const float* prow = p + (long)(rok ? row0 + row : nrows - 1) * ld;
+                if (vec) {
+                    r[i] = *reinterpret_cast<const f32x4*>(prow + (k0 + kq));
+                } else {
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    r[i][e] = (rok && (k0 + kq + e) < kend) ? src[e] : 0.0f;
+                    for (int e = 0; e < 4; ++e) v[e] = prow[min(k0 + kq + e, kend - 1)];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[i][e] = (rok && (k0 + kq + e) < kend) ? v[e] : 0.0f;
+                }
             }
         } else {
             const int kr = idx / (ROWS / 4), rq = (idx % (ROWS / 4)) * 4;
-            const float* src = p + (long)(k0 + kr) * ld + (row0 + rq);
             if (!EDGE) {
-                r[i] = *reinterpret_cast<const f32x4*>(src);
+                r[i] = *reinterpret_cast<const f32x4*>(p + (long)(k0 + kr) * ld + (row0 + rq));
             } else {
                 const bool kok = (k0 + kr) < kend;
+                const float* pk = p + (long)(kok ? k0 + kr : kend - 1) * ld;
+                if (vec) {
+                    r[i] = *reinterpret_cast<const f32x4*>(pk + (row0 + rq));
+                } else {
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    r[i][e] = (kok && (row0 + rq + e) < nrows) ? src[e] : 0.0f;
+                    for (int e = 0; e < 4; ++e) v[e] = pk[min(row0 + rq + e, nrows - 1)];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[i][e] = (kok && (row0 + rq + e) < nrows) ? v[e] : 0.0f;
+                }
             }
         }
     }
@@ -330,6 +349,12 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
         ncol_end = p.N;
     }
 
+    // bounds-checked instantiation: may this tile's panels still use 16-byte loads? (see panel_gload)
+    const bool a_al = EDGE && ((p.al_mask >> (mt >= p.tiles_m1 ? 1 : 0)) & 1) &&
+                      (ALAY == KMAJOR || mA0 + BM <= nArows);
+    const bool b_al = EDGE && ((p.al_mask >> (nt >= p.tiles_n1 ? 3 : 2)) & 1) &&
+                      (BLAY == KMAJOR || nB0 + BN <= nBrows);
+
     if constexpr (MF == 16) {
         // ---- v_mfma_f32_16x16x4_f32 form: (WM/16) x (WN/16) accumulators of 4 registers ----
         static_assert(BK == 16 && Cfg::PIPE == 0, "16x16x4 form: BK = 16, plain schedule");
@@ -344,8 +369,8 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
         f32x4 ra[GA::F4], rb[GB::F4];
         const int nkb = (kend - kbeg + BK - 1) / BK;
         if (nkb > 0) {
-            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, kbeg, kend, tid);
-            panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
+            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, kbeg, kend, tid, a_al && (kbeg) + BK <= kend);
+            panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid, b_al && (kbeg) + BK <= kend);
             panel_lds_store<ALAY, BM, BK, NT, MF>(sA0, ra, tid);
             panel_lds_store<BLAY, BN, BK, NT, MF>(sB0, rb, tid);
         }
@@ -357,8 +382,8 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
             const bool more = (kb + 1) < nkb;
             if (more) {
                 const int k0 = kbeg + (kb + 1) * BK;
-                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid);
-                panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid, a_al && (k0) + BK <= kend);
+                panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid, b_al && (k0) + BK <= kend);
             }
             f32x4 fa[T16M], fb[T16N];
 #pragma unroll
@@ -419,8 +444,8 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     const int nkb = (kend - kbeg + BK - 1) / BK;
 
     if (nkb > 0) {
-        panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, kbeg, kend, tid);
-        panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
+        panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, kbeg, kend, tid, a_al && (kbeg) + BK <= kend);
+        panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid, b_al && (kbeg) + BK <= kend);
         panel_lds_store<ALAY, BM, BK, NT, MF>(sA0, ra, tid);
         panel_lds_store<BLAY, BN, BK, NT, MF>(sB0, rb, tid);
     }
@@ -449,8 +474,8 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
             }
             if (more) {  // next block's global loads, behind the LDS reads in issue order
                 const int k0 = kbeg + (kb + 1) * BK;
-                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid);
-                panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid, a_al && (k0) + BK <= kend);
+                panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid, b_al && (k0) + BK <= kend);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -477,8 +502,8 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
             const bool more = (kb + 1) < nkb;
             if (more) {  // issue next block's global loads; they land during the MFMAs
                 const int k0 = kbeg + (kb + 1) * BK;
-                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid);
-                panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid, a_al && (k0) + BK <= kend);
+                panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid, b_al && (k0) + BK <= kend);
             }
     #pragma unroll
             for (int c = 0; c < BK / 8; ++c) {
@@ -520,8 +545,8 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
             for (int j = 0; j < TN; ++j) fb[j] = panel_frag<BLAY, BN, BK>(sB0, wn * WN + j * 32 + l31, 0, h);
         }
         if (nkb > 1) {
-            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, kbeg + BK, kend, tid);
-            panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg + BK, kend, tid);
+            panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, kbeg + BK, kend, tid, a_al && (kbeg + BK) + BK <= kend);
+            panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg + BK, kend, tid, b_al && (kbeg + BK) + BK <= kend);
         }
         for (int kb = 0; kb < nkb; ++kb) {
             const int cur = kb & 1;
@@ -546,8 +571,8 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
                     __syncthreads();
                     if ((kb + 2) < nkb) {
                         const int k0 = kbeg + (kb + 2) * BK;
-                        panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid);
-                        panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+                        panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid, a_al && (k0) + BK <= kend);
+                        panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid, b_al && (k0) + BK <= kend);
                     }
                     if (more) {
 #pragma unroll
@@ -683,6 +708,8 @@ inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi&
     if (p.B2 != nullptr) fast = fast && (p.n_b1 % BN == 0) && (p.ldb2 % 4 == 0) && al16(p.B2);
     if (p.A2 != nullptr) fast = fast && (p.m_a1 % BM == 0) && (p.lda2 % 4 == 0) && al16(p.A2);
     p.vec_epi = (fast && epi_vec_ok(epi)) ? 1 : 0;
+    p.al_mask = ((al16(p.A) && p.lda % 4 == 0) ? 1 : 0) | ((p.A2 != nullptr && al16(p.A2) && p.lda2 % 4 == 0) ? 2 : 0) |
+                ((al16(p.B) && p.ldb % 4 == 0) ? 4 : 0) | ((p.B2 != nullptr && al16(p.B2) && p.ldb2 % 4 == 0) ? 8 : 0);
     const int grid = p.tiles_m * p.tiles_n * p.ksplits;
     if (grid <= 0) return hipSuccess;
     constexpr int lds_bytes = 8 * (PanelGeom<ALAY, BM, BK, Cfg::NTHREADS>::ELEMS +
