@@ -45,6 +45,7 @@ struct GemmProblemD {
     int tiles_m, tiles_n;
     int tiles_n1;
     int mt_fast;
+    int al_mask = 0;   // set by the launcher: bit 0 / 2 / 3 = A / B / B2 is 16-byte aligned with an even ld
 };
 
 template <int BM_, int BN_, int WM_, int WN_, int MINW_>
@@ -73,9 +74,13 @@ struct PanelD {
     }
 };
 
+// EDGE as in the fp32 core (panel_gload): `vec` (wave-uniform) = operand 16-byte aligned, whole K block
+// inside, row-contiguous panels only with the whole tile inside -> 16-byte loads with the row clamped;
+// otherwise element-wise loads from clamped addresses and a select (no load under a lane predicate).
 template <int LAY, int ROWS, bool EDGE, int NT_, int CH>
 __device__ __forceinline__ void panel_gload_d(f64x2 (&r)[CH], const double* __restrict__ p, long ld,
-                                              int row0, int nrows, int k0, int kend, int tid) {
+                                              int row0, int nrows, int k0, int kend, int tid,
+                                              bool vec = false) {
     static_assert(CH == PanelD<LAY, ROWS, NT_>::CH, "register panel size");
     constexpr int BK = 16;
 #pragma unroll
@@ -83,23 +88,37 @@ __device__ __forceinline__ void panel_gload_d(f64x2 (&r)[CH], const double* __re
         const int idx = tid + i * NT_;
         if (LAY == KMAJOR) {
             const int row = idx / (BK / 2), kq = (idx % (BK / 2)) * 2;
-            const double* src = p + (long)(row0 + row) * ld + (k0 + kq);
             if (!EDGE) {
-                r[i] = *reinterpret_cast<const f64x2*>(src);
+                r[i] = *reinterpret_cast<const f64x2*>(p + (long)(row0 + row) * ld + (k0 + kq));
             } else {
                 const bool rok = (row0 + row) < nrows;
+                const double* prow = p + (long)(rok ? row0 + row : nrows - 1) * ld;
+                if (vec) {
+                    r[i] = *reinterpret_cast<const f64x2*>(prow + (k0 + kq));
+                } else {
+                    double v[2];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) r[i][e] = (rok && (k0 + kq + e) < kend) ? src[e] : 0.0;
+                    for (int e = 0; e < 2; ++e) v[e] = prow[min(k0 + kq + e, kend - 1)];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) r[i][e] = (rok && (k0 + kq + e) < kend) ? v[e] : 0.0;
+                }
             }
         } else {
             const int kr = idx / (ROWS / 2), rq = (idx % (ROWS / 2)) * 2;
-            const double* src = p + (long)(k0 + kr) * ld + (row0 + rq);
             if (!EDGE) {
-                r[i] = *reinterpret_cast<const f64x2*>(src);
+                r[i] = *reinterpret_cast<const f64x2*>(p + (long)(k0 + kr) * ld + (row0 + rq));
             } else {
                 const bool kok = (k0 + kr) < kend;
+                const double* pk = p + (long)(kok ? k0 + kr : kend - 1) * ld;
+                if (vec) {
+                    r[i] = *reinterpret_cast<const f64x2*>(pk + (row0 + rq));
+                } else {
+                    double v[2];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) r[i][e] = (kok && (row0 + rq + e) < nrows) ? src[e] : 0.0;
+                    for (int e = 0; e < 2; ++e) v[e] = pk[min(row0 + rq + e, nrows - 1)];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) r[i][e] = (kok && (row0 + rq + e) < nrows) ? v[e] : 0.0;
+                }
             }
         }
     }
@@ -190,6 +209,11 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) gemm_mfma_f64_kernel(GemmP
         ncol_end = p.N;
     }
 
+    // bounds-checked instantiation: may this tile's panels still use 16-byte loads? (see panel_gload_d)
+    const bool a_al = EDGE && (p.al_mask & 1) && (ALAY == KMAJOR || m0 + BM <= p.M);
+    const bool b_al = EDGE && ((p.al_mask >> (nt >= p.tiles_n1 ? 3 : 2)) & 1) &&
+                      (BLAY == KMAJOR || nB0 + BN <= nBrows);
+
     f64x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -199,8 +223,8 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) gemm_mfma_f64_kernel(GemmP
     f64x2 ra[GA::CH], rb[GB::CH];
     const int nkb = (kend - kbeg + BK - 1) / BK;
     if (nkb > 0) {
-        panel_gload_d<ALAY, BM, EDGE, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
-        panel_gload_d<BLAY, BN, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid);
+        panel_gload_d<ALAY, BM, EDGE, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid, a_al && (kbeg) + BK <= kend);
+        panel_gload_d<BLAY, BN, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, kbeg, kend, tid, b_al && (kbeg) + BK <= kend);
         panel_lds_store_d<ALAY, BM, NT>(sA0, ra, tid);
         panel_lds_store_d<BLAY, BN, NT>(sB0, rb, tid);
     }
@@ -213,8 +237,8 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) gemm_mfma_f64_kernel(GemmP
         const bool more = (kb + 1) < nkb;
         if (more) {
             const int k0 = kbeg + (kb + 1) * BK;
-            panel_gload_d<ALAY, BM, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
-            panel_gload_d<BLAY, BN, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid);
+            panel_gload_d<ALAY, BM, EDGE, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, tid, a_al && (k0) + BK <= kend);
+            panel_gload_d<BLAY, BN, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid, b_al && (k0) + BK <= kend);
         }
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
@@ -288,6 +312,8 @@ inline hipError_t launch_gemm_mfma_f64_cfg(hipStream_t stream, GemmProblemD p, c
     bool fast = (p.M % BM == 0) && (p.N % BN == 0) && (p.K % BK == 0) && (p.klen % BK == 0) &&
                 (p.lda % 2 == 0) && (p.ldb % 2 == 0) && al16(p.A) && al16(p.B) && p.K > 0;
     if (p.B2 != nullptr) fast = fast && (p.n_b1 % BN == 0) && (p.ldb2 % 2 == 0) && al16(p.B2);
+    p.al_mask = ((al16(p.A) && p.lda % 2 == 0) ? 1 : 0) | ((al16(p.B) && p.ldb % 2 == 0) ? 4 : 0) |
+                ((p.B2 != nullptr && al16(p.B2) && p.ldb2 % 2 == 0) ? 8 : 0);
     const int grid = p.tiles_m * p.tiles_n * p.ksplits;
     if (grid <= 0) return hipSuccess;
     constexpr int lds_bytes = 16 * (PanelD<ALAY, BM, Cfg::NT>::ELEMS + PanelD<BLAY, BN, Cfg::NT>::ELEMS);
