@@ -156,11 +156,12 @@ typedef TileCfg<128, 128, 16, 64, 64, 2> CfgLarge;     // 4 waves, 32 KiB LDS ->
 typedef TileCfg<128, 128, 16, 64, 32, 2> CfgMid;       // 8 waves: mid-size outputs (128..511 tiles), e.g.
                                                       // y.A^H / v.AAt of an 8192-row minibatch: +8 % over 64x64
 typedef TileCfg<64, 64, 16, 32, 32, 2> CfgSmall;
-typedef TileCfg<32, 128, 32, 32, 32, 2> CfgFlat;       // <= 32 output rows (atom-block residuals)
+typedef TileCfg<32, 128, 32, 32, 32, 2> CfgFlat;       // <= 32 output rows (x^T [Y|x] with <= 32 atoms)
+typedef TileCfg<128, 32, 32, 32, 32, 2> CfgTall;       // <= 32 output columns (Y.D^T, x.G with <= 32 atoms)
 typedef TileCfg<64, 64, 64, 32, 32, 1> CfgSmallDeep;   // 64 KiB LDS: latency-bound products on few CUs (64-row
                                                       // atom-block GEMMs): 4x fewer, 4x larger K blocks in flight
 
-enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2, TIER_FLAT = 3, TIER_MID = 4, TIER_SMALL_DEEP = 5 };
+enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2, TIER_FLAT = 3, TIER_MID = 4, TIER_SMALL_DEEP = 5, TIER_TALL = 6 };
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
@@ -168,6 +169,7 @@ inline void tier_dims(int tier, int& bm, int& bn) {
     if (tier == TIER_HUGE) { bm = CfgHuge::BM; bn = CfgHuge::BN; }
     else if (tier == TIER_LARGE || tier == TIER_MID) { bm = CfgLarge::BM; bn = CfgLarge::BN; }
     else if (tier == TIER_FLAT) { bm = CfgFlat::BM; bn = CfgFlat::BN; }
+    else if (tier == TIER_TALL) { bm = CfgTall::BM; bn = CfgTall::BN; }
     else { bm = 64; bn = 64; }
 }
 
@@ -180,6 +182,13 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
     if (tile_sel == TILE_SMALL_DEEP) return TIER_SMALL_DEEP;
     if (tile_sel == TILE_LARGE) return TIER_LARGE;
     if (tile_sel == TILE_HUGE) return FORM == FORM_TN ? TIER_LARGE : TIER_HUGE;
+    // <= 64 output rows or columns (<= 64 atoms): a 128-wide tile would idle half of every MFMA and run
+    // bounds-checked (Y.D^T 65536 x 64 x 4096: 0.60 ms on 128x128, 0.34 ms on 64x64; x^T Y 64 x 4160 x 65536: 1.07 -> 0.39 ms)
+    // <= 32 (the usual NMF ranks): 32-wide tiles; these products are HBM bound (Y is read once per product:
+    // Y.D^T 65536 x 32 x 4096 0.40 ms on 64x64, 0.22 ms = 4.9 TB/s on 128x32; x^T Y 32 x 4128 x 65536 0.53 -> 0.32 ms)
+    if (M <= 32 && N > 32) return TIER_FLAT;
+    if (N <= 32 && M > 32) return TIER_TALL;
+    if (M <= 64 || N <= 64) return TIER_SMALL;
     long splits = will_split ? K / 512 : 1;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
@@ -310,6 +319,8 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         }
         if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL, Epi>(stream, p, epi);
         if (tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmallDeep, AL, BL, Epi>(stream, p, epi);
+        if (tier == TIER_FLAT) return launch_gemm_mfma<CfgFlat, AL, BL, Epi>(stream, p, epi);
+        if (tier == TIER_TALL) return launch_gemm_mfma<CfgTall, AL, BL, Epi>(stream, p, epi);
         if constexpr (FORM != FORM_TN) {
             if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL, Epi>(stream, p, epi);
             if (tier == TIER_MID) return launch_gemm_mfma<CfgMid, AL, BL, Epi>(stream, p, epi);
@@ -336,7 +347,8 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     p.M = 2 * a.M; p.N = 2 * a.N; p.K = a.K;
                     CplxTnEpi<Epi> ce{epi};
                     const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
-                    if (tier == TIER_SMALL || tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
+                    if (tier == TIER_SMALL || tier == TIER_SMALL_DEEP || tier == TIER_FLAT || tier == TIER_TALL)
+                        return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
                 } else if (cplx_planar_a<FORM>(a.M, a.N, a.conjA, a.conjB, a.ext_ws)) {
                     // rows(A): [2M, K] real image in the caller's scratch (2MK <= 4KN reals); B as it lies
@@ -356,7 +368,8 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     CplxNnEpi<Epi> ce{epi};
                     const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
                     if (tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmallDeep, AL, BL>(stream, p, ce);
-                    if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
+                    if (tier == TIER_SMALL || tier == TIER_FLAT || tier == TIER_TALL)
+                        return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
                 } else {
                     // ext(B): [2 rows(B), 2 cols(B)] real image in the caller's scratch
@@ -372,7 +385,8 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     if (a.ksplits <= 1) p.klen = 0;
                     CplxColEpi<Epi> ce{epi};
                     const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
-                    if (tier == TIER_SMALL || tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
+                    if (tier == TIER_SMALL || tier == TIER_SMALL_DEEP || tier == TIER_FLAT || tier == TIER_TALL)
+                        return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
                     if (tier == TIER_HUGE) return launch_gemm_mfma<CfgHuge, AL, BL>(stream, p, ce);
                     if (tier == TIER_MID) return launch_gemm_mfma<CfgMid, AL, BL>(stream, p, ce);
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);

@@ -84,6 +84,17 @@ typedef TileCfg<128, 128, 16, 64, 64, 2, 0, 16> CfgLargeMf16;  // 24: 128x128 / 
 typedef TileCfg<256, 256, 16, 64, 64, 1, 2> Cfg16wAhead;       // 25: all fragment reads of a K block up front
 typedef TileCfg<128, 128, 16, 64, 64, 2, 2> CfgLargeAhead;     // 26: same, 128x128 / 4 waves
 
+// narrow outputs (<= 64 atoms): 64-wide tiles (NT / NN) and 64-tall tiles (TN)
+typedef TileCfg<128, 64, 16, 32, 64, 2> CfgTall128;     // 27: 4 waves of 32x64
+typedef TileCfg<256, 64, 16, 64, 64, 2> CfgTall256;     // 28: 4 waves of 64x64
+typedef TileCfg<64, 128, 16, 64, 32, 2> CfgFlat128;     // 29: 4 waves of 64x32 (TN: 64 output rows)
+typedef TileCfg<64, 256, 16, 64, 64, 2> CfgFlat256;     // 30: 4 waves of 64x64
+
+typedef TileCfg<256, 32, 32, 64, 32, 2> CfgTall32;      // 31: 4 waves of 64x32, BK = 32 (<= 32 atoms)
+typedef TileCfg<128, 32, 32, 32, 32, 2> CfgTall32s;     // 32: 4 waves of 32x32, BK = 32
+typedef TileCfg<32, 256, 32, 32, 64, 2> CfgFlat32;      // 33: 4 waves of 32x64, BK = 32 (TN, <= 32 atoms)
+typedef TileCfg<32, 128, 32, 32, 32, 2> CfgFlat32s;     // 34: 4 waves of 32x32, BK = 32
+
 template <class Cfg, int FORM, class Epi>
 hipError_t hook_cfg(hipStream_t st, const GemmArgs<float>& a, const Epi& epi) {
     GemmProblem p;
@@ -154,6 +165,14 @@ hipError_t gemm_hook_launch(hipStream_t st, const GemmArgs<T>& a, int tile, cons
             case 24: return hook_cfg<CfgLargeMf16, FORM>(st, a, epi);
             case 25: return hook_cfg<Cfg16wAhead, FORM>(st, a, epi);
             case 26: return hook_cfg<CfgLargeAhead, FORM>(st, a, epi);
+            case 27: return hook_cfg<CfgTall128, FORM>(st, a, epi);
+            case 28: return hook_cfg<CfgTall256, FORM>(st, a, epi);
+            case 29: return hook_cfg<CfgFlat128, FORM>(st, a, epi);
+            case 30: return hook_cfg<CfgFlat256, FORM>(st, a, epi);
+            case 31: return hook_cfg<CfgTall32, FORM>(st, a, epi);
+            case 32: return hook_cfg<CfgTall32s, FORM>(st, a, epi);
+            case 33: return hook_cfg<CfgFlat32, FORM>(st, a, epi);
+            case 34: return hook_cfg<CfgFlat32s, FORM>(st, a, epi);
             default: break;
         }
     }

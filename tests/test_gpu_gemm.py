@@ -27,7 +27,7 @@ SHAPES_RAGGED = [(101, 20, 3), (37, 65, 129), (1, 1, 1), (3, 101, 20), (130, 258
 
 
 @pytest.mark.parametrize('form', [0, 1, 2])
-@pytest.mark.parametrize('tile', list(range(0, 27)))
+@pytest.mark.parametrize('tile', list(range(0, 35)))
 def test_f32_aligned(form, tile):
     rng = np.random.RandomState(form * 10 + tile)
     for (M, N, K) in SHAPES_ALIGNED:
@@ -38,7 +38,7 @@ def test_f32_aligned(form, tile):
 
 
 @pytest.mark.parametrize('form', [0, 1, 2])
-@pytest.mark.parametrize('tile', list(range(0, 27)))
+@pytest.mark.parametrize('tile', list(range(0, 35)))
 def test_f32_ragged(form, tile):
     rng = np.random.RandomState(100 + form * 10 + tile)
     for (M, N, K) in SHAPES_RAGGED:
