@@ -206,11 +206,40 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
     return TIER_SMALL;
 }
 
-// float64 products big enough for the 128 x 128 fp64 MFMA tile; smaller ones stay on the
-// generic 64 x 64 core (more workgroups for thin outputs).
+// float64 products big enough for the 128 x 128 fp64 MFMA tile (complex128 on real-extended operands
+// uses this predicate; real float64 has the finer f64_tier below).
 inline bool f64_on_mfma(int M, int N, int tile_sel) {
     if (tile_sel == TILE_SMALL || tile_sel == TILE_SMALL_DEEP) return false;
     return M >= 128 && N >= 128;
+}
+
+// float64 (the reference's default dtype) tiles on the fp64 MFMA core.  Narrow outputs -- the usual NMF
+// ranks of 8 .. 64 atoms -- get 32- and 64-wide tiles; before, anything under 128 fell to the generic VALU core
+// (MU iteration 16384 x 4096, float64: k = 100 2.06 ms, k = 64 0.92, k = 32 0.84, k = 8 0.79 ms).
+enum F64Tier { F64_GENERIC = 0, F64_128 = 1, F64_TALL64 = 2, F64_TALL32 = 3, F64_FLAT64 = 4, F64_FLAT32 = 5 };
+typedef F64Cfg<128, 64, 32, 32, 1> F64Tall64;   // 8 waves of 32 x 32
+typedef F64Cfg<128, 32, 32, 32, 2> F64Tall32;   // 4 waves
+typedef F64Cfg<64, 128, 32, 32, 1> F64Flat64;   // 8 waves
+typedef F64Cfg<32, 128, 32, 32, 2> F64Flat32;   // 4 waves
+
+inline int f64_tier(int M, int N, int tile_sel) {
+    if (tile_sel == TILE_SMALL || tile_sel == TILE_SMALL_DEEP) return F64_GENERIC;
+    if (M > 64 && N > 64) return F64_128;
+    if (N <= 32 && M >= 128) return F64_TALL32;
+    if (N <= 64 && M >= 128) return F64_TALL64;
+    if (M <= 32 && N >= 128) return F64_FLAT32;
+    if (M <= 64 && N >= 128) return F64_FLAT64;
+    return F64_GENERIC;
+}
+inline bool f64_tier_dims(int tier, int& bm, int& bn) {
+    switch (tier) {
+        case F64_128: bm = 128; bn = 128; return true;
+        case F64_TALL64: bm = 128; bn = 64; return true;
+        case F64_TALL32: bm = 128; bn = 32; return true;
+        case F64_FLAT64: bm = 64; bn = 128; return true;
+        case F64_FLAT32: bm = 32; bn = 128; return true;
+        default: return false;
+    }
 }
 
 // Choose split-K so that the grid reaches ~target workgroups, each split a multiple
@@ -229,7 +258,7 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_b
         else Kx *= 2;
     }
     if (mfma) tier_dims(pick_tier<FORM>(Mx, Nx, Kx, a.tile, true), bm, bn);
-    if (std::is_same<T, double>::value && f64_on_mfma(a.M, a.N, a.tile)) { bm = F64Tile::BM; bn = F64Tile::BN; }
+    if (std::is_same<T, double>::value) (void)f64_tier_dims(f64_tier(a.M, a.N, a.tile), bm, bn);
     if (std::is_same<T, c128>::value && cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws)) {
         const int Me = (FORM == FORM_TN) ? 2 * a.M : a.M;
         if (f64_on_mfma(Me, 2 * a.N, a.tile)) {      // real-extended problem on the fp64 MFMA core
@@ -431,7 +460,8 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
             }
         }
         if constexpr (std::is_same<T, double>::value) {
-            if (f64_on_mfma(a.M, a.N, a.tile)) {
+            const int t64 = f64_tier(a.M, a.N, a.tile);
+            if (t64 != F64_GENERIC) {
                 GemmProblemD p;
                 p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb;
                 p.B2 = a.B2; p.ldb2 = a.ldb2; p.n_b1 = a.n_b1;
@@ -441,6 +471,10 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                 p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
                 constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
                 constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
+                if (t64 == F64_TALL64) return launch_gemm_mfma_f64_cfg<F64Tall64, AL, BL, Epi>(stream, p, epi);
+                if (t64 == F64_TALL32) return launch_gemm_mfma_f64_cfg<F64Tall32, AL, BL, Epi>(stream, p, epi);
+                if (t64 == F64_FLAT64) return launch_gemm_mfma_f64_cfg<F64Flat64, AL, BL, Epi>(stream, p, epi);
+                if (t64 == F64_FLAT32) return launch_gemm_mfma_f64_cfg<F64Flat32, AL, BL, Epi>(stream, p, epi);
                 return launch_gemm_mfma_f64<AL, BL, Epi>(stream, p, epi);
             }
         }

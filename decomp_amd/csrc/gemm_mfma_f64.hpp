@@ -66,8 +66,8 @@ struct PanelD {
     static constexpr int BK = 16;
     static constexpr int XSTRIDE = ROWS + 16;
     static constexpr int ELEMS = (LAY == KMAJOR) ? ROWS * BK : BK * XSTRIDE;
-    static constexpr int CH = ROWS * BK / 2 / NT_;   // 16-byte chunks per thread per block
-    static_assert(ROWS * BK % (2 * NT_) == 0, "panel must be whole chunks per thread");
+    static constexpr int CH = ROWS * BK / 2 / NT_;   // 16-byte chunks per thread per block (checked by the loaders)
+    static constexpr bool WHOLE = (ROWS * BK % (2 * NT_) == 0) && CH > 0;
     // double offset of 16-byte chunk q (2 doubles) of row r in the swizzled KMAJOR image
     __device__ static __forceinline__ int kchunk(int r, int q) {
         return r * BK + ((q ^ ((r >> 1) & 7)) << 1);
@@ -82,6 +82,7 @@ __device__ __forceinline__ void panel_gload_d(f64x2 (&r)[CH], const double* __re
                                               int row0, int nrows, int k0, int kend, int tid,
                                               bool vec = false) {
     static_assert(CH == PanelD<LAY, ROWS, NT_>::CH, "register panel size");
+    static_assert(PanelD<LAY, ROWS, NT_>::WHOLE, "panel must be whole chunks per thread");
     constexpr int BK = 16;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
