@@ -285,6 +285,22 @@ def secondary_configs(torch, device):
                                           'value': round(ms, 4), 'tflops': round(Ws / ms / 1e9, 1),
                                           'compute_side_speedup_at_8_gpus': None}
     del Y, Ys, xs, Ds, x
+    # the usual NMF ranks are far below the headline's 256 atoms: same Y shape as configs[1] per 16384 rows, k = 32
+    # (narrow 128x32 / 32x128 tiles; the step is bound by reading Y twice)
+    N, F, K = 16384, 4096, 32
+    Yk = torch.rand((N, F), generator=g, device=device)
+    Dk = torch.rand((K, F), generator=g, device=device) + 0.1
+    _arrays.l2_normalize_(Dk, strict=True)
+    xk = torch.ones((N, K), device=device)
+
+    def rank32(n=10):
+        _hip.check(h, lib.dcp_nmf_mu_f32(h, _arrays.ptr(Yk), None, _arrays.ptr(xk), _arrays.ptr(Dk), N, F, K,
+                                         _hip.LIK_L2, ctypes.c_float(0.0), n + 1, ctypes.byref(it), None, None),
+                   'nmf_mu k=32')
+    ms = ms_of(rank32, 3) / 10
+    out['rank32_nmf_ms_per_iter'] = {'workload': '16384x4096 k=32 fp32 (narrow tiles)', 'value': round(ms, 4),
+                                     'hbm_gbs_on_2_reads_of_Y': round(2.0 * N * F * 4 / ms / 1e6, 0)}
+    del Yk, Dk, xk
     # configs[4]: one complex64 dictionary-learning minibatch step at one GPU's shape, 8192 x 8192, k = 512
     MB, F, K = 8192, 8192, 512
 

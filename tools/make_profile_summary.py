@@ -24,7 +24,7 @@ def main():
     out_dir = os.path.join(root, 'profiles')
     os.makedirs(out_dir, exist_ok=True)
     # kernel stats
-    ks = glob.glob(os.path.join(src, 'kt', '*', '*_kernel_stats.csv'))[0]
+    ks = sorted(glob.glob(os.path.join(src, 'kt', '*', '*_kernel_stats.csv')), key=os.path.getmtime)[-1]
     rows = list(csv.DictReader(open(ks)))
     with open(os.path.join(out_dir, tag + '_kernel_stats.csv'), 'w') as f:
         f.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py   (default: --gpus 1 --steps 50 --warmup 5)\n')
