@@ -5,7 +5,7 @@ import torch
 from decomp_amd import _arrays, _hip
 lib = _hip.load()
 for (N, F, K) in [(65536, 4096, 256), (65536, 4096, 250), (65536, 4096, 252), (65000, 4000, 256), (65536, 4096, 64),
-                  (65536, 4096, 50), (65536, 4096, 32), (65536, 4096, 20), (65536, 4096, 8), (65536, 4090, 256)]:
+                  (65536, 4096, 50), (65536, 4096, 32), (65536, 4096, 30), (65536, 4096, 20), (65536, 4096, 10), (65536, 4096, 8), (65536, 4090, 256)]:
     g = torch.Generator(device='cuda'); g.manual_seed(0)
     Y = torch.rand((N, F), generator=g, device='cuda')
     D = torch.rand((K, F), generator=g, device='cuda') + 0.1
