@@ -136,13 +136,20 @@ __global__ void __launch_bounds__(256) mask_rowbits_kernel(const R* __restrict__
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
         const long g = i / cols, c = i - g * cols;
         uint32_t w = 0;
-#pragma unroll 8
-        for (int b = 0; b < 32; ++b) {
-            const long r = g * 32 + b;
-            if (r < rows) {
-                const R m = mask[r * cols + c];
-                if (m != R(0)) w |= (1u << b);
-                if (m != R(0) && m != R(1)) bad = true;
+        // eight rows in flight per round: unconditional loads from a clamped row, selected afterwards
+        // (a load under `if (r < rows)` is a branch and a full wait of its own)
+        for (int b0 = 0; b0 < 32; b0 += 8) {
+            R m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long r = g * 32 + b0 + u;
+                m[u] = mask[(r < rows ? r : rows - 1) * cols + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = (g * 32 + b0 + u) < rows;
+                if (in && m[u] != R(0)) w |= (1u << (b0 + u));
+                if (in && m[u] != R(0) && m[u] != R(1)) bad = true;
             }
         }
         bits[i] = w;
