@@ -205,12 +205,14 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
         long s = ksplits > kblocks ? kblocks : ksplits;
         a.klen = (int)(((kblocks + s - 1) / s) * 16);
         a.ksplits = (int)((K + a.klen - 1) / a.klen);
+        // slabs for the larger of the two plans (complex products may re-plan over the real-extended 2K below)
+        const size_t max_slabs = (size_t)(ksplits > a.ksplits ? ksplits : a.ksplits) + 1;
         WsPlan plan;
-        plan.add<T>((size_t)a.ksplits * M * N);
+        plan.add<T>(max_slabs * M * N);
         plan.add<RT>(ext_floats + 4);
         DCP_TRY(ws_reserve(h, plan.total));
         ws_reset(h);
-        T* slabs = ws_alloc<T>(h, (size_t)a.ksplits * M * N);
+        T* slabs = ws_alloc<T>(h, max_slabs * M * N);
         ext = ws_alloc<RT>(h, ext_floats + 4);
         if (!slabs || !ext) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
         if (ext_floats) {
@@ -222,6 +224,7 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
                 long s2 = ksplits > kb2 ? kb2 : ksplits;
                 a.klen = (int)(((kb2 + s2 - 1) / s2) * 16);
                 a.ksplits = (int)((2 * K + a.klen - 1) / a.klen);
+                if ((size_t)a.ksplits > max_slabs) return fail(h, DCP_ERR_INTERNAL, "hook slab plan");
             }
         }
         EpiSlab<T> epi{slabs, (long)N, (long)M * N};

@@ -164,3 +164,43 @@ def test_c128_on_mfma(form):
             C = gemm_hip(form, A, B, ksplits=ks, tile=tile)
             err = np.abs(C - ref) / bound
             assert err.max() < 1e-14, (form, M, N, K, ks, tile, err.max())
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64, np.complex64, np.complex128])
+def test_random_shapes_auto_dispatch(dtype):
+    """Seeded random shapes through the AUTOMATIC tile choice (tile 0), all three forms, with and
+    without split-K: every tier of pick_tier / f64_tier, the bounds-checked loaders (clamped 16-byte
+    loads on aligned operands, element-wise loads on odd leading dimensions) and the complex paths
+    (extended image, planar rows, TN real views)."""
+    rng = np.random.RandomState({np.float32: 1, np.float64: 2, np.complex64: 3, np.complex128: 4}[dtype])
+    cplx = np.issubdtype(dtype, np.complexfloating)
+    tol = 2e-5 if dtype in (np.float32, np.complex64) else 1e-13
+    sizes = [1, 3, 8, 20, 31, 32, 33, 50, 64, 65, 100, 127, 128, 129, 200, 250, 256, 260, 300, 500, 512, 777, 1024, 2050]
+    for trial in range(60):
+        M, N = int(rng.choice(sizes)), int(rng.choice(sizes))
+        K = int(rng.choice([1, 5, 16, 33, 64, 100, 256, 511, 1024, 3000]))
+        if trial % 7 == 0:
+            M = int(rng.choice([4096, 5000, 8192]))     # tall: the big row-tile tiers
+        form = trial % 3
+        ks = int(rng.choice([1, 1, 2, 5]))
+
+        def mk(*s):
+            a = rng.randn(*s)
+            if cplx:
+                a = a + 1j * rng.randn(*s)
+            return a.astype(dtype)
+        if form == 0:
+            A, B = mk(M, K), mk(N, K)
+            ref = A.astype(np.complex128 if cplx else np.float64) @ B.astype(np.complex128 if cplx else np.float64).conj().T
+            bound = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T
+        elif form == 1:
+            A, B = mk(M, K), mk(K, N)
+            ref = A.astype(np.complex128 if cplx else np.float64) @ B.astype(np.complex128 if cplx else np.float64)
+            bound = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+        else:
+            A, B = mk(K, M), mk(K, N)
+            ref = A.astype(np.complex128 if cplx else np.float64).conj().T @ B.astype(np.complex128 if cplx else np.float64)
+            bound = np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)
+        C = gemm_hip(form, A, B, ksplits=ks, tile=0)
+        err = np.abs(C - ref) / (bound + 1e-300)
+        assert err.max() < tol, (dtype, form, M, N, K, ks, float(err.max()))
