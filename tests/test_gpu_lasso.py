@@ -161,3 +161,40 @@ def test_masked_against_oracle_medium_fp32(method, mask_kind):
     assert it == ito
     assert _err(x, xo) < 2e-4, _err(x, xo)
     assert np.count_nonzero(x) > 0
+
+
+@pytest.mark.parametrize('dt', ['float32', 'float64', 'complex64', 'complex128'])
+def test_random_shapes_against_oracle(dt):
+    """Seeded random (samples, channels, atoms) off every tile grid, all gradient methods and masks of
+    every rank, 20 iterations without early stop: the same iterate as the oracle (lasso.py restated)."""
+    from decomp_amd import lasso
+    from oracle import lasso as olasso
+    cplx = dt.startswith('complex')
+    rng = np.random.RandomState({'float32': 11, 'float64': 12, 'complex64': 13, 'complex128': 14}[dt])
+    tol = 3e-4 if dt in ('float32', 'complex64') else 1e-9
+    methods = ['ista', 'acc_ista', 'fista'] + ([] if cplx else ['ista_pos', 'fista_pos'])
+    for trial in range(14):
+        N = int(rng.choice([1, 7, 33, 100, 257, 1000, 2049]))
+        F = int(rng.choice([5, 30, 64, 100, 130, 250, 517]))
+        K = int(rng.choice([3, 8, 20, 33, 64, 100, 129, 200]))
+        method = methods[trial % len(methods)]
+        mkind = trial % 3
+
+        def randn(*s):
+            return (rng.randn(*s) + 1j * rng.randn(*s)) if cplx else rng.randn(*s)
+        A = randn(K, F)
+        xt = randn(N, K) * (rng.uniform(size=(N, K)) < 0.2)
+        y = (xt @ A + 0.1 * randn(N, F)).astype(dt)
+        A = A.astype(dt)
+        mask = None
+        if mkind == 1:
+            mask = np.rint(rng.uniform(0.3, 1.0, size=F)).astype(y.real.dtype)
+        elif mkind == 2:
+            mask = np.rint(rng.uniform(0.3, 1.0, size=(N, F))).astype(y.real.dtype)
+        it, x = lasso.solve(y.copy(), A.copy(), 0.05, tol=1e-12, method=method, maxiter=20,
+                            mask=None if mask is None else mask.copy())
+        ito, xo = olasso.solve(y.copy(), A.copy(), 0.05, tol=1e-12, method=method, maxiter=20,
+                               mask=None if mask is None else mask.copy())
+        assert x.shape == xo.shape and x.dtype == y.dtype
+        e = _err(x, xo)
+        assert e < tol, (dt, trial, N, F, K, method, mkind, e)

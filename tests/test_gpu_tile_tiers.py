@@ -34,6 +34,37 @@ def _residual(y, x, d, m):
     return float(np.sqrt(np.sum(r * r)))
 
 
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('shape', [(4096, 1024, 8), (4096, 1024, 50), (4099, 1021, 30), (4096, 1024, 128), (4100, 1028, 64)])
+@pytest.mark.parametrize('masked', [False, True])
+def test_kl_iterations_match_oracle(shape, dtype, masked):
+    """The Kullback-Leibler update (grads.py:143-160) through the same tiers: its [N, F] ratio products
+    take the narrow tiles on both sides."""
+    import torch
+    from decomp_amd import _arrays, _hip
+    from oracle import nmf as onmf, common
+    N, F, K = shape
+    y, d0, m = _problem(N, F, K, dtype, masked, seed=7 + N + F + K)
+    Yg, Dg = torch.from_numpy(y).cuda(), torch.from_numpy(d0).cuda()
+    Mg = None if m is None else torch.from_numpy(m).cuda()
+    _arrays.l2_normalize_(Dg, strict=True)
+    xg = torch.ones((N, K), device='cuda', dtype=Yg.dtype)
+    lib, h = _arrays.lib_handle(Yg)
+    sfx = 'f32' if dtype == np.float32 else 'f64'
+    ctype = ctypes.c_float if dtype == np.float32 else ctypes.c_double
+    fn = getattr(lib, 'dcp_nmf_mu_' + sfx)
+    it = ctypes.c_int(0)
+    x, d = np.ones((N, K), dtype), common.l2_strict(d0)
+    tol_x, tol_d = (2e-4, 2e-4) if dtype == np.float32 else (1e-10, 1e-10)
+    for step in range(3):
+        _hip.check(h, fn(h, _arrays.ptr(Yg), _arrays.ptr(Mg), _arrays.ptr(xg), _arrays.ptr(Dg), N, F, K,
+                         _hip.LIK_KL, ctype(0.0), 2, ctypes.byref(it), None, None), 'dcp_nmf_mu kl')
+        x, d, _ = onmf.mu_step(y, x, d, m, 'kl')
+        dx = float(np.max(np.abs(xg.cpu().numpy() - x)) / max(1.0, float(np.max(np.abs(x)))))
+        dd = float(np.max(np.abs(Dg.cpu().numpy() - d)))
+        assert dx <= tol_x and dd <= tol_d, (shape, dtype, masked, step, dx, dd)
+
+
 @pytest.mark.parametrize('masked', [False, True])
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
 @pytest.mark.parametrize('shape', SHAPES)
