@@ -87,7 +87,11 @@ def test_golden_single_precision_and_wide(name):
                                     ('float32', 33, 96),
                                     # float32 with K, F multiples of 64: the fused three-launch path
                                     # (csrc/atom_fused_f32.hpp), 1 / 3 / 4 blocks
-                                    ('float32', 64, 128), ('float32', 192, 128), ('float32', 256, 320)])
+                                    ('float32', 64, 128), ('float32', 192, 128), ('float32', 256, 320),
+                                    # ragged channel counts (bounds-checked products), complex64 on the
+                                    # planar-rows products with 2, 3 and 4 blocks of 32 atoms
+                                    ('float32', 128, 100), ('complex64', 96, 130), ('complex64', 64, 256),
+                                    ('complex64', 128, 67), ('float64', 96, 130)])
 def test_atom_sweep_direct_against_oracle(dt, K, F):
     """dcp_dict_update_* alone (A/B accumulation + the blocked Gauss-Seidel atom sweep + max|dD|)
     against oracle.dictionary_learning.atom_sweep (dictionary_learning.py:154-159) for dictionaries
