@@ -153,8 +153,10 @@ inline bool cplx_on_mfma(bool conjA, bool conjB, const void* ext_ws) {
 // 128x128, whose 68 tiles x 15 splits fill one round of 1024 resident workgroups.
 typedef TileCfg<256, 256, 16, 64, 64, 1> CfgHuge;      // 16 waves, 64 KiB LDS
 typedef TileCfg<128, 128, 16, 64, 64, 2> CfgLarge;     // 4 waves, 32 KiB LDS -> 4 WG/CU
-typedef TileCfg<128, 128, 16, 64, 32, 2> CfgMid;       // 8 waves: mid-size outputs (128..511 tiles), e.g.
-                                                      // y.A^H / v.AAt of an 8192-row minibatch: +8 % over 64x64
+typedef TileCfg<128, 128, 64, 32, 64, 2> CfgMid;       // 8 waves of 32x64, 64-deep K blocks (128 KiB LDS): mid-size
+                                                      // outputs (128..511 tiles, at most one per CU), e.g. y.A^H of
+                                                      // an 8192-row minibatch, 8192 x 512 x 4096: 0.292 ms with 16-deep
+                                                      // blocks, 0.275 ms with 64-deep ones (vendor BLAS: 0.263 ms)
 typedef TileCfg<64, 64, 16, 32, 32, 2> CfgSmall;
 typedef TileCfg<32, 128, 32, 32, 32, 2> CfgFlat;       // <= 32 output rows (x^T [Y|x] with <= 32 atoms)
 typedef TileCfg<128, 32, 32, 32, 32, 2> CfgTall;       // <= 32 output columns (Y.D^T, x.G with <= 32 atoms)
