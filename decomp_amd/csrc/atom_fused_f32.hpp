@@ -189,7 +189,7 @@ inline int atom_sweep_fused_f32(dcp_handle* h, const float* A, const float* B, f
     DCP_LAUNCH_OK(h, hipGetLastError());
     {
         static DynLdsRaised raised;
-        bool& r = raised.on_current_device();
+        std::atomic<bool>& r = raised.on_current_device();
         if (!r) {
             DCP_LAUNCH_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&atom_recur_lookahead_kernel<float>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,

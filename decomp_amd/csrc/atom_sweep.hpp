@@ -384,7 +384,7 @@ inline int atom_sweep(dcp_handle* h, const T* A, const T* B, T* Dnew, int64_t F6
     DCP_LAUNCH_OK(h, hipGetLastError());
     {
         static DynLdsRaised raised;   // per dtype
-        bool& r = raised.on_current_device();
+        std::atomic<bool>& r = raised.on_current_device();
         if (!r) {
             DCP_LAUNCH_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&atom_recur_kernel<T>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -33,6 +33,7 @@
 // k in [s*klen, min(K, (s+1)*klen)).  The epilogue receives the split index.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -677,9 +678,14 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
 
 // hipFuncSetAttribute is per device: remember per (kernel instantiation, device) whether the
 // dynamic-LDS cap has been raised (one process normally drives one GPU, but nothing here assumes it).
+// (atomic flags: handles of different host threads may launch the same instantiation; raising the cap twice
+//  is harmless, a torn flag is not)
 struct DynLdsRaised {
-    bool done[32] = {false};
-    bool& on_current_device() {
+    std::atomic<bool> done[32];
+    DynLdsRaised() {
+        for (auto& d : done) d.store(false, std::memory_order_relaxed);
+    }
+    std::atomic<bool>& on_current_device() {
         int dev = 0;
         (void)hipGetDevice(&dev);
         return done[(dev >= 0 && dev < 32) ? dev : 0];
@@ -717,7 +723,7 @@ inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi&
     constexpr int dyn_bytes = lds_bytes > 65536 ? lds_bytes : 0;
     if (dyn_bytes) {
         static DynLdsRaised raised_fast, raised_edge;   // per instantiation
-        bool& raised = fast ? raised_fast.on_current_device() : raised_edge.on_current_device();
+        std::atomic<bool>& raised = fast ? raised_fast.on_current_device() : raised_edge.on_current_device();
         if (!raised) {
             const void* fn = fast ? reinterpret_cast<const void*>(&gemm_mfma_kernel<Cfg, ALAY, BLAY, false, Epi>)
                                   : reinterpret_cast<const void*>(&gemm_mfma_kernel<Cfg, ALAY, BLAY, true, Epi>);

@@ -321,7 +321,7 @@ inline hipError_t launch_gemm_mfma_f64_cfg(hipStream_t stream, GemmProblemD p, c
     constexpr int dyn_bytes = lds_bytes > 65536 ? lds_bytes : 0;
     if (dyn_bytes) {
         static DynLdsRaised raised_fast, raised_edge;   // per instantiation
-        bool& raised = fast ? raised_fast.on_current_device() : raised_edge.on_current_device();
+        std::atomic<bool>& raised = fast ? raised_fast.on_current_device() : raised_edge.on_current_device();
         if (!raised) {
             const void* fn = fast ? reinterpret_cast<const void*>(&gemm_mfma_f64_kernel<Cfg, ALAY, BLAY, false, Epi>)
                                   : reinterpret_cast<const void*>(&gemm_mfma_f64_kernel<Cfg, ALAY, BLAY, true, Epi>);

@@ -383,7 +383,7 @@ static int move_rows(dcp_handle* h, const void* in, const int64_t* in_index, voi
         // workgroup keep every other workgroup off them -- which is plenty to saturate the link
         // (12 x 64 KiB in flight) and costs the overlapped compute < 5 % of the chip.
         static DynLdsRaised raised_flag;
-        bool& raised = raised_flag.on_current_device();
+        std::atomic<bool>& raised = raised_flag.on_current_device();
         const int lds_bytes = 160 * 1024;
         if (!raised) {
             DCP_HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&move_rows_kernel<4>),
