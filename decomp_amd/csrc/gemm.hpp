@@ -160,15 +160,17 @@ typedef TileCfg<128, 128, 64, 32, 64, 2> CfgMid;       // 8 waves of 32x64, 64-d
 typedef TileCfg<64, 64, 16, 32, 32, 2> CfgSmall;
 typedef TileCfg<32, 128, 32, 32, 32, 2> CfgFlat;       // <= 32 output rows (x^T [Y|x] with <= 32 atoms)
 typedef TileCfg<128, 32, 32, 32, 32, 2> CfgTall;       // <= 32 output columns (Y.D^T, x.G with <= 32 atoms)
+typedef TileCfg<256, 256, 32, 64, 64, 1> CfgHugeDeep;   // 16 waves, 32-deep K blocks (128 KiB LDS): x^T [y|x] with >= 512
+                                                      // atoms (dictionary step, 512 x 4608 x 8192, 7 splits: 0.362 -> 0.328 ms)
 typedef TileCfg<64, 64, 64, 32, 32, 1> CfgSmallDeep;   // 64 KiB LDS: latency-bound products on few CUs (64-row
                                                       // atom-block GEMMs): 4x fewer, 4x larger K blocks in flight
 
-enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2, TIER_FLAT = 3, TIER_MID = 4, TIER_SMALL_DEEP = 5, TIER_TALL = 6 };
+enum Tier { TIER_SMALL = 0, TIER_LARGE = 1, TIER_HUGE = 2, TIER_FLAT = 3, TIER_MID = 4, TIER_SMALL_DEEP = 5, TIER_TALL = 6, TIER_HUGE_DEEP = 7 };
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 inline void tier_dims(int tier, int& bm, int& bn) {
-    if (tier == TIER_HUGE) { bm = CfgHuge::BM; bn = CfgHuge::BN; }
+    if (tier == TIER_HUGE || tier == TIER_HUGE_DEEP) { bm = CfgHuge::BM; bn = CfgHuge::BN; }
     else if (tier == TIER_LARGE || tier == TIER_MID) { bm = CfgLarge::BM; bn = CfgLarge::BN; }
     else if (tier == TIER_FLAT) { bm = CfgFlat::BM; bn = CfgFlat::BN; }
     else if (tier == TIER_TALL) { bm = CfgTall::BM; bn = CfgTall::BN; }
@@ -179,7 +181,7 @@ inline void tier_dims(int tier, int& bm, int& bn) {
 // launch): the largest tile that still gives the chip enough workgroups, counting the splits
 // a deep reduction allows.
 template <int FORM>
-inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
+inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split, bool real32 = false) {
     if (tile_sel == TILE_SMALL) return TIER_SMALL;
     if (tile_sel == TILE_SMALL_DEEP) return TIER_SMALL_DEEP;
     if (tile_sel == TILE_LARGE) return TIER_LARGE;
@@ -194,6 +196,9 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split) {
     long splits = will_split ? K / 512 : 1;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
+    // reduction over samples with a tall output (>= 512 atoms), split over the samples: the big tile with deep
+    // K blocks (float32 problems only: the complex paths launch 64- or 128-wide tiles for this form)
+    if (FORM == FORM_TN && real32 && will_split && M >= 512 && N >= 512 && tile_sel == TILE_AUTO) return TIER_HUGE_DEEP;
     if (FORM != FORM_TN) {
         const long wh = (long)ceil_div(M, CfgHuge::BM) * ceil_div(N, CfgHuge::BN);
         // (N in (128, 256), (384, 512), ...: the 256-wide tile covers no more columns than 128-wide tiles would:
@@ -262,7 +267,16 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_b
         if (FORM == FORM_TN || cplx_planar_a<FORM>(a.M, a.N, a.conjA, a.conjB, a.ext_ws)) Mx *= 2;
         else Kx *= 2;
     }
-    if (mfma) tier_dims(pick_tier<FORM>(Mx, Nx, Kx, a.tile, true), bm, bn);
+    int kunit = 1;   // K blocks of 16 per K block of the tile that will run (splits are whole tile blocks)
+    if (mfma) {
+        const int tier = pick_tier<FORM>(Mx, Nx, Kx, a.tile, true, std::is_same<T, float>::value);
+        tier_dims(tier, bm, bn);
+        if (std::is_same<T, float>::value) {
+            if (tier == TIER_HUGE_DEEP) kunit = CfgHugeDeep::BK / 16;
+            if (tier == TIER_MID) kunit = CfgMid::BK / 16;
+        }
+    }
+    if (mfma && FORM == FORM_TN && bm == CfgHuge::BM && target_wgs > 256) target_wgs = 256;   // one 16-wave tile per CU
     if (std::is_same<T, double>::value) (void)f64_tier_dims(f64_tier(a.M, a.N, a.tile), bm, bn);
     if (std::is_same<T, c128>::value && cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws)) {
         const int Me = (FORM == FORM_TN) ? 2 * a.M : a.M;
@@ -296,7 +310,8 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_b
         }
         s = best_s;
     }
-    const long blocks_per_split = (kblocks + s - 1) / s;
+    long blocks_per_split = (kblocks + s - 1) / s;
+    blocks_per_split = ((blocks_per_split + kunit - 1) / kunit) * kunit;
     a.klen = (int)(blocks_per_split * 16);   // in units of the core's reduction index (see gemm())
     a.ksplits = ceil_div(Kx > 0 ? Kx : 1, a.klen);
     return a.ksplits;
@@ -342,7 +357,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
         constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
         constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
-        int tier = pick_tier<FORM>(a.M, a.N, a.K, a.tile, a.split_planned);
+        int tier = pick_tier<FORM>(a.M, a.N, a.K, a.tile, a.split_planned, true);
         if (tier == TIER_SMALL && a.tile == TILE_AUTO) {
             // at most one workgroup per CU: occupancy is moot and the product is a chain of
             // load -> LDS -> MFMA round trips, one per K block; 64-deep blocks make 4x fewer of them
@@ -353,6 +368,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         }
         if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL, Epi>(stream, p, epi);
         if (tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmallDeep, AL, BL, Epi>(stream, p, epi);
+        if (tier == TIER_HUGE_DEEP) return launch_gemm_mfma<CfgHugeDeep, AL, BL, Epi>(stream, p, epi);
         if (tier == TIER_FLAT) return launch_gemm_mfma<CfgFlat, AL, BL, Epi>(stream, p, epi);
         if (tier == TIER_TALL) return launch_gemm_mfma<CfgTall, AL, BL, Epi>(stream, p, epi);
         if constexpr (FORM != FORM_TN) {
