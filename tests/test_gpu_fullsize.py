@@ -321,3 +321,45 @@ def test_c4_shard_masked_fp32_trace_matches_fp64(lik):
     r64 = trace(Y.double(), mask.double(), D0.double(), 'f64', ctypes.c_double)
     rel = np.abs(r32 - r64) / r64
     assert rel.max() <= 1e-5, rel
+
+
+def test_more_than_2_pow_32_elements():
+    """Y 1048576 x 4096 (4.3e9 elements, 17 GB), k = 64: every index computation beyond 32 bits.  Two MU
+    iterations decrease the residual, and the last 4096 rows carry exactly their share of it (an index that
+    wrapped would leave the upper half of x untouched or garbage)."""
+    import ctypes
+    import torch
+    from decomp_amd import _arrays, _hip
+    n, f, k = 1 << 20, 4096, 64
+    g = torch.Generator(device='cuda')
+    g.manual_seed(0)
+    Dt = torch.rand((k, f), generator=g, device='cuda')
+    xt = torch.rand((n, k), generator=g, device='cuda')
+    Y = torch.empty((n, f), device='cuda')
+    for r0 in range(0, n, 1 << 16):
+        Y[r0:r0 + (1 << 16)] = xt[r0:r0 + (1 << 16)] @ Dt
+    del xt
+    Y += 0.05 * torch.rand((n, f), generator=g, device='cuda')
+    D = Dt + 0.3 * torch.rand((k, f), generator=g, device='cuda')
+    _arrays.l2_normalize_(D, strict=True)
+    x = torch.ones((n, k), device='cuda')
+    lib, h = _arrays.lib_handle(D)
+    it = ctypes.c_int(0)
+
+    def resid():
+        out = ctypes.c_double(0)
+        _hip.check(h, lib.dcp_nmf_residual_f32(h, _arrays.ptr(Y), None, _arrays.ptr(x), _arrays.ptr(D), n, f, k,
+                                               ctypes.byref(out)), 'resid')
+        return out.value
+    r_prev = resid()
+    for _ in range(2):
+        _hip.check(h, lib.dcp_nmf_mu_f32(h, _arrays.ptr(Y), None, _arrays.ptr(x), _arrays.ptr(D), n, f, k,
+                                         _hip.LIK_L2, ctypes.c_float(0.0), 2, ctypes.byref(it), None, None), 'nmf')
+        r = resid()
+        assert r < r_prev and np.isfinite(r)
+        r_prev = r
+    assert bool(torch.isfinite(x).all())
+    tail = Y[-4096:] - x[-4096:] @ D
+    r_tail = float((tail.double() ** 2).sum().sqrt())
+    assert abs(r_tail - r_prev / 16.0) < 0.02 * r_tail, (r_tail, r_prev / 16.0)     # 4096 of 2^20 rows: 1/256 of the squares
+    assert abs(float(x[-4096:].mean()) - float(x[:4096].mean())) < 0.01 * float(x[:4096].mean())
