@@ -363,3 +363,26 @@ def test_more_than_2_pow_32_elements():
     r_tail = float((tail.double() ** 2).sum().sqrt())
     assert abs(r_tail - r_prev / 16.0) < 0.02 * r_tail, (r_tail, r_prev / 16.0)     # 4096 of 2^20 rows: 1/256 of the squares
     assert abs(float(x[-4096:].mean()) - float(x[:4096].mean())) < 0.01 * float(x[:4096].mean())
+
+
+def test_lasso_rows_beyond_2_pow_31_elements():
+    """lasso.solve on y 600000 x 4096 (2.46e9 elements): the rows of a LASSO problem are independent, so the
+    last 2048 rows solved on their own must give the same codes as inside the big solve."""
+    import torch
+    from decomp_amd import lasso
+    n, f, k = 600000, 4096, 64
+    g = torch.Generator(device='cuda')
+    g.manual_seed(5)
+    A = torch.randn((k, f), generator=g, device='cuda')
+    y = torch.empty((n, f), device='cuda')
+    for r0 in range(0, n, 50000):
+        xt = torch.randn((50000, k), generator=g, device='cuda') * (torch.rand((50000, k), generator=g, device='cuda') < 0.1)
+        y[r0:r0 + 50000] = xt @ A
+    y += 0.1 * torch.randn((n, f), generator=g, device='cuda')
+    it, x = lasso.solve(y, A, 0.1, tol=1e-12, method='ista', maxiter=6)
+    it2, x_tail = lasso.solve(y[-2048:].clone(), A, 0.1, tol=1e-12, method='ista', maxiter=6)
+    assert it == it2
+    assert bool(torch.isfinite(x).all())
+    d = float((x[-2048:] - x_tail).abs().max())
+    assert d <= 1e-6 * max(1.0, float(x_tail.abs().max())), d
+    assert int((x[-2048:] != 0).sum()) > 0
