@@ -216,14 +216,8 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split, bool re
     return TIER_SMALL;
 }
 
-// float64 products big enough for the 128 x 128 fp64 MFMA tile (complex128 on real-extended operands
-// uses this predicate; real float64 has the finer f64_tier below).
-inline bool f64_on_mfma(int M, int N, int tile_sel) {
-    if (tile_sel == TILE_SMALL || tile_sel == TILE_SMALL_DEEP) return false;
-    return M >= 128 && N >= 128;
-}
-
-// float64 (the reference's default dtype) tiles on the fp64 MFMA core.  Narrow outputs -- the usual NMF
+// float64 (the reference's default dtype) and complex128 (on real-extended operands) tiles on the fp64 MFMA
+// core.  Narrow outputs -- the usual NMF
 // ranks of 8 .. 64 atoms -- get 32- and 64-wide tiles; before, anything under 128 fell to the generic VALU core
 // (MU iteration 16384 x 4096, float64: k = 100 2.06 ms, k = 64 0.92, k = 32 0.84, k = 8 0.79 ms).
 enum F64Tier { F64_GENERIC = 0, F64_128 = 1, F64_TALL64 = 2, F64_TALL32 = 3, F64_FLAT64 = 4, F64_FLAT32 = 5 };
@@ -250,6 +244,15 @@ inline bool f64_tier_dims(int tier, int& bm, int& bn) {
         case F64_FLAT32: bm = 32; bn = 128; return true;
         default: return false;
     }
+}
+
+template <int AL, int BL, class Epi>
+inline hipError_t launch_f64_tier(int tier, hipStream_t stream, const GemmProblemD& p, const Epi& epi) {
+    if (tier == F64_TALL64) return launch_gemm_mfma_f64_cfg<F64Tall64, AL, BL, Epi>(stream, p, epi);
+    if (tier == F64_TALL32) return launch_gemm_mfma_f64_cfg<F64Tall32, AL, BL, Epi>(stream, p, epi);
+    if (tier == F64_FLAT64) return launch_gemm_mfma_f64_cfg<F64Flat64, AL, BL, Epi>(stream, p, epi);
+    if (tier == F64_FLAT32) return launch_gemm_mfma_f64_cfg<F64Flat32, AL, BL, Epi>(stream, p, epi);
+    return launch_gemm_mfma_f64<AL, BL, Epi>(stream, p, epi);
 }
 
 // Choose split-K so that the grid reaches ~target workgroups, each split a multiple
@@ -280,10 +283,11 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_b
     if (std::is_same<T, double>::value) (void)f64_tier_dims(f64_tier(a.M, a.N, a.tile), bm, bn);
     if (std::is_same<T, c128>::value && cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws)) {
         const int Me = (FORM == FORM_TN) ? 2 * a.M : a.M;
-        if (f64_on_mfma(Me, 2 * a.N, a.tile)) {      // real-extended problem on the fp64 MFMA core
+        int tbm = 0, tbn = 0;
+        if (f64_tier_dims(f64_tier(Me, 2 * a.N, a.tile), tbm, tbn)) {   // real-extended problem on the fp64 MFMA core
             Mx = Me; Nx = 2 * a.N; n1 *= 2;
             if (FORM != FORM_TN) Kx *= 2;
-            bm = F64Tile::BM; bn = F64Tile::BN;
+            bm = tbm; bn = tbn;
         }
     }
     const long tiles = (long)ceil_div(Mx, bm) * (ceil_div(n1, bn) + ceil_div(Nx - n1, bn));
@@ -445,7 +449,8 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         }
         if constexpr (std::is_same<T, c128>::value) {
             const int Me = (FORM == FORM_TN) ? 2 * a.M : a.M;
-            if (cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws) && f64_on_mfma(Me, 2 * a.N, a.tile)) {
+            const int t128 = f64_tier(Me, 2 * a.N, a.tile);
+            if (cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws) && t128 != F64_GENERIC) {
                 // complex128 on the fp64 MFMA core: same real-extended formulation as complex64
                 GemmProblemD p;
                 p.A = reinterpret_cast<const double*>(a.A); p.lda = 2 * a.lda;
@@ -463,7 +468,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     }
                     p.M = 2 * a.M; p.N = 2 * a.N; p.K = a.K;
                     CplxTnEpi<Epi, double> ce{epi};
-                    return launch_gemm_mfma_f64<AL, BL>(stream, p, ce);
+                    return launch_f64_tier<AL, BL>(t128, stream, p, ce);
                 } else {
                     const long rowsB = (FORM == FORM_NT) ? a.N : a.K;
                     const long colsB = (FORM == FORM_NT) ? a.K : a.N;
@@ -476,7 +481,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     p.M = a.M; p.N = 2 * a.N; p.K = 2 * a.K;
                     if (a.ksplits <= 1) p.klen = 0;
                     CplxColEpi<Epi, double> ce{epi};
-                    return launch_gemm_mfma_f64<AL, BL>(stream, p, ce);
+                    return launch_f64_tier<AL, BL>(t128, stream, p, ce);
                 }
             }
         }
@@ -492,11 +497,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                 p.mt_fast = (FORM == FORM_NT) ? 0 : 1;
                 constexpr int AL = (FORM == FORM_TN) ? XMAJOR : KMAJOR;
                 constexpr int BL = (FORM == FORM_NT) ? KMAJOR : XMAJOR;
-                if (t64 == F64_TALL64) return launch_gemm_mfma_f64_cfg<F64Tall64, AL, BL, Epi>(stream, p, epi);
-                if (t64 == F64_TALL32) return launch_gemm_mfma_f64_cfg<F64Tall32, AL, BL, Epi>(stream, p, epi);
-                if (t64 == F64_FLAT64) return launch_gemm_mfma_f64_cfg<F64Flat64, AL, BL, Epi>(stream, p, epi);
-                if (t64 == F64_FLAT32) return launch_gemm_mfma_f64_cfg<F64Flat32, AL, BL, Epi>(stream, p, epi);
-                return launch_gemm_mfma_f64<AL, BL, Epi>(stream, p, epi);
+                return launch_f64_tier<AL, BL>(t64, stream, p, epi);
             }
         }
         GenericProblem<T> p;
