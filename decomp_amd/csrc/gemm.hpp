@@ -227,7 +227,9 @@ typedef F64Cfg<64, 128, 32, 32, 1> F64Flat64;   // 8 waves
 typedef F64Cfg<32, 128, 32, 32, 2> F64Flat32;   // 4 waves
 
 inline int f64_tier(int M, int N, int tile_sel) {
-    if (tile_sel == TILE_SMALL || tile_sel == TILE_SMALL_DEEP) return F64_GENERIC;
+    // (TILE_SMALL_DEEP -- the atom sweep's 64-row block products -- is a float32 tile choice; in double precision
+    //  those products take the 64 x 128 tile here: the generic core needed 113 us for the 64 x 4096 x 512 one)
+    if (tile_sel == TILE_SMALL) return F64_GENERIC;
     if (M > 64 && N > 64) return F64_128;
     if (N <= 32 && M >= 128) return F64_TALL32;
     if (N <= 64 && M >= 128) return F64_TALL64;
