@@ -300,7 +300,7 @@ struct AtomWs {
     T* slabs = nullptr;  // split-K partials of G
     size_t slab_count = 0;
     real_t<T>* ext = nullptr;   // complex: real extended images (max(4KF, 4*64*F) reals)
-    // complex64: planar-rows images of Ablk, Alook [2K, K], Aprev [2K, 64] and E [128, 64]
+    // complex: planar-rows images of Ablk, Alook [2K, K], Aprev [2K, 64] and E [128, 64]
     real_t<T>* rows_blk = nullptr;
     real_t<T>* rows_look = nullptr;
     real_t<T>* rows_prev = nullptr;
@@ -325,7 +325,7 @@ inline void atom_plan(WsPlan& p, int64_t F, int64_t K) {
     p.add<T>((size_t)K);
     p.add<T>(atom_slab_elems(F));
     if (scalar_traits<T>::is_complex) p.add<real_t<T> >((size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
-    if (std::is_same<T, c64>::value) {
+    if (scalar_traits<T>::is_complex) {
         p.add<real_t<T> >((size_t)2 * K * K);
         p.add<real_t<T> >((size_t)2 * K * K);
         p.add<real_t<T> >((size_t)2 * K * kAtomBlkMax);
@@ -349,7 +349,7 @@ inline int atom_carve(dcp_handle* h, AtomWs<T>& w, int64_t F, int64_t K) {
         w.ext = ws_alloc<real_t<T> >(h, (size_t)4 * (K > kAtomBlkMax ? K : kAtomBlkMax) * F);
         if (!w.ext) return fail(h, DCP_ERR_INTERNAL, "atom sweep workspace plan");
     }
-    if (std::is_same<T, c64>::value) {
+    if (scalar_traits<T>::is_complex) {
         w.rows_blk = ws_alloc<real_t<T> >(h, (size_t)2 * K * K);
         w.rows_look = ws_alloc<real_t<T> >(h, (size_t)2 * K * K);
         w.rows_prev = ws_alloc<real_t<T> >(h, (size_t)2 * K * kAtomBlkMax);

@@ -286,9 +286,11 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_b
     if (std::is_same<T, c128>::value && cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws)) {
         const int Me = (FORM == FORM_TN) ? 2 * a.M : a.M;
         int tbm = 0, tbn = 0;
-        if (f64_tier_dims(f64_tier(Me, 2 * a.N, a.tile), tbm, tbn)) {   // real-extended problem on the fp64 MFMA core
-            Mx = Me; Nx = 2 * a.N; n1 *= 2;
-            if (FORM != FORM_TN) Kx *= 2;
+        const bool planar = cplx_planar_a<FORM>(a.M, a.N, a.conjA, a.conjB, a.ext_ws) &&
+                            f64_tier(2 * a.M, 2 * a.N, a.tile) != F64_GENERIC;
+        if (f64_tier_dims(f64_tier(planar ? 2 * a.M : Me, 2 * a.N, a.tile), tbm, tbn)) {   // fp64 MFMA core
+            Mx = planar ? 2 * a.M : Me; Nx = 2 * a.N; n1 *= 2;
+            if (FORM != FORM_TN && !planar) Kx *= 2;
             bm = tbm; bn = tbn;
         }
     }
@@ -471,6 +473,24 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     p.M = 2 * a.M; p.N = 2 * a.N; p.K = a.K;
                     CplxTnEpi<Epi, double> ce{epi};
                     return launch_f64_tier<AL, BL>(t128, stream, p, ce);
+                } else if (cplx_planar_a<FORM>(a.M, a.N, a.conjA, a.conjB, a.ext_ws) &&
+                           f64_tier(2 * a.M, 2 * a.N, a.tile) != F64_GENERIC) {
+                    // planar rows of A against B's own memory, as for complex64 (mode 3)
+                    if (a.A_rows != nullptr) {
+                        p.A = a.A_rows; p.lda = a.lda_rows;
+                    } else {
+                        long g = ((long)a.M * a.K + 255) / 256;
+                        if (g > 4096) g = 4096;
+                        if (g < 1) g = 1;
+                        hipLaunchKernelGGL((cplx_rows_kernel<double>), dim3((unsigned)g), dim3(256), 0, stream, a.A,
+                                           (long)a.M, (long)a.K, a.lda, a.ext_ws);
+                        p.A = a.ext_ws; p.lda = a.K;
+                    }
+                    p.B = reinterpret_cast<const double*>(a.B); p.ldb = 2 * a.ldb;
+                    p.M = 2 * a.M; p.N = 2 * a.N; p.K = a.K;
+                    if (a.ksplits <= 1) p.klen = 0;
+                    CplxNnEpi<Epi, double> ce{epi};
+                    return launch_f64_tier<AL, BL>(f64_tier(p.M, p.N, a.tile), stream, p, ce);
                 } else {
                     const long rowsB = (FORM == FORM_NT) ? a.N : a.K;
                     const long colsB = (FORM == FORM_NT) ? a.K : a.N;

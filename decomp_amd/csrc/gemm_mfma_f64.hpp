@@ -286,11 +286,14 @@ __global__ void __launch_bounds__(Cfg::NT, Cfg::MINW) gemm_mfma_f64_kernel(GemmP
                     if (!(lane & 1) && (!EDGE || (row < p.M && col < ncol_end)))
                         epi.pair(row, col >> 1, v, o, split);
                 } else {
+                    // mode 2 (x^H y): re = rr + ii, im = ri - ir ;  mode 3 (planar rows of x times y): re = rr - ii, im = ri + ir
                     const double ii = __shfl_xor(v, 17, 64);
                     const double ri = __shfl_xor(v, 1, 64);
                     const double ir = __shfl_xor(v, 16, 64);
-                    if (!(lane & 1) && !(g & 1) && (!EDGE || (row < p.M && col < ncol_end)))
-                        epi.pair(row >> 1, col >> 1, v + ii, ri - ir, split);
+                    if (!(lane & 1) && !(g & 1) && (!EDGE || (row < p.M && col < ncol_end))) {
+                        if constexpr (MODE == 2) epi.pair(row >> 1, col >> 1, v + ii, ri - ir, split);
+                        else epi.pair(row >> 1, col >> 1, v - ii, ri + ir, split);
+                    }
                 }
             }
         }

@@ -217,8 +217,8 @@ int gemm_api(dcp_handle* h, int form, const T* A, const T* B, T* C, int64_t M, i
         if (!slabs || !ext) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
         if (ext_floats) {
             a.ext_ws = ext;
-            const bool planar = std::is_same<T, c64>::value && form == FORM_NN &&
-                                cplx_planar_a<FORM_NN>(a.M, a.N, a.conjA, a.conjB, a.ext_ws);
+            bool planar = form == FORM_NN && cplx_planar_a<FORM_NN>(a.M, a.N, a.conjA, a.conjB, a.ext_ws);
+            if (std::is_same<T, c128>::value) planar = planar && f64_tier(2 * a.M, 2 * a.N, a.tile) != F64_GENERIC;
             if (form != FORM_TN && !planar) {   // the MFMA core splits the real-extended reduction (2K)
                 const long kb2 = (2 * K + 15) / 16;
                 long s2 = ksplits > kb2 ? kb2 : ksplits;
