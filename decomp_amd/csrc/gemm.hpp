@@ -220,7 +220,8 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split, bool re
 // core.  Narrow outputs -- the usual NMF
 // ranks of 8 .. 64 atoms -- get 32- and 64-wide tiles; before, anything under 128 fell to the generic VALU core
 // (MU iteration 16384 x 4096, float64: k = 100 2.06 ms, k = 64 0.92, k = 32 0.84, k = 8 0.79 ms).
-enum F64Tier { F64_GENERIC = 0, F64_128 = 1, F64_TALL64 = 2, F64_TALL32 = 3, F64_FLAT64 = 4, F64_FLAT32 = 5 };
+enum F64Tier { F64_GENERIC = 0, F64_128 = 1, F64_TALL64 = 2, F64_TALL32 = 3, F64_FLAT64 = 4, F64_FLAT32 = 5, F64_SQ64 = 6 };
+typedef F64Cfg<64, 64, 32, 32, 1> F64Sq64;      // 4 waves: block Gram matrices of the atom sweep (deep reduction, split)
 typedef F64Cfg<128, 64, 32, 32, 1> F64Tall64;   // 8 waves of 32 x 32
 typedef F64Cfg<128, 32, 32, 32, 2> F64Tall32;   // 4 waves
 typedef F64Cfg<64, 128, 32, 32, 1> F64Flat64;   // 8 waves
@@ -235,6 +236,7 @@ inline int f64_tier(int M, int N, int tile_sel) {
     if (N <= 64 && M >= 128) return F64_TALL64;
     if (M <= 32 && N >= 128) return F64_FLAT32;
     if (M <= 64 && N >= 128) return F64_FLAT64;
+    if (M > 32 && N > 32) return F64_SQ64;   // (33..64) x (33..64 or 65..127 handled above): small square outputs
     return F64_GENERIC;
 }
 inline bool f64_tier_dims(int tier, int& bm, int& bn) {
@@ -244,6 +246,7 @@ inline bool f64_tier_dims(int tier, int& bm, int& bn) {
         case F64_TALL32: bm = 128; bn = 32; return true;
         case F64_FLAT64: bm = 64; bn = 128; return true;
         case F64_FLAT32: bm = 32; bn = 128; return true;
+        case F64_SQ64: bm = 64; bn = 64; return true;
         default: return false;
     }
 }
@@ -254,6 +257,7 @@ inline hipError_t launch_f64_tier(int tier, hipStream_t stream, const GemmProble
     if (tier == F64_TALL32) return launch_gemm_mfma_f64_cfg<F64Tall32, AL, BL, Epi>(stream, p, epi);
     if (tier == F64_FLAT64) return launch_gemm_mfma_f64_cfg<F64Flat64, AL, BL, Epi>(stream, p, epi);
     if (tier == F64_FLAT32) return launch_gemm_mfma_f64_cfg<F64Flat32, AL, BL, Epi>(stream, p, epi);
+    if (tier == F64_SQ64) return launch_gemm_mfma_f64_cfg<F64Sq64, AL, BL, Epi>(stream, p, epi);
     return launch_gemm_mfma_f64<AL, BL, Epi>(stream, p, epi);
 }
 
