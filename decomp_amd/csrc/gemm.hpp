@@ -227,11 +227,16 @@ typedef F64Cfg<128, 32, 32, 32, 2> F64Tall32;   // 4 waves
 typedef F64Cfg<64, 128, 32, 32, 1> F64Flat64;   // 8 waves
 typedef F64Cfg<32, 128, 32, 32, 2> F64Flat32;   // 4 waves
 
-inline int f64_tier(int M, int N, int tile_sel) {
+inline int f64_tier(int M, int N, int tile_sel, int K = 1 << 30) {
     // (TILE_SMALL_DEEP -- the atom sweep's 64-row block products -- is a float32 tile choice; in double precision
     //  those products take the 64 x 128 tile here: the generic core needed 113 us for the 64 x 4096 x 512 one)
     if (tile_sel == TILE_SMALL) return F64_GENERIC;
-    if (M > 64 && N > 64) return F64_128;
+    if (M > 64 && N > 64) {
+        // few 128 x 128 tiles (the D-side products of an MU step: 256 x 4096 -> 64 tiles on 256 CUs): 64 x 64 tiles
+        // put four times as many workgroups on the chip; these products are latency bound
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        return (t128 < 96 && K <= 1024) ? F64_SQ64 : F64_128;   // (shallow reductions only)
+    }
     if (N <= 32 && M >= 128) return F64_TALL32;
     if (N <= 64 && M >= 128) return F64_TALL64;
     if (M <= 32 && N >= 128) return F64_FLAT32;
@@ -286,7 +291,7 @@ inline int plan_splits(GemmArgs<T>& a, int target_wgs, int max_splits, int min_b
         }
     }
     if (mfma && FORM == FORM_TN && bm == CfgHuge::BM && target_wgs > 256) target_wgs = 256;   // one 16-wave tile per CU
-    if (std::is_same<T, double>::value) (void)f64_tier_dims(f64_tier(a.M, a.N, a.tile), bm, bn);
+    if (std::is_same<T, double>::value) (void)f64_tier_dims(f64_tier(a.M, a.N, a.tile, a.K), bm, bn);
     if (std::is_same<T, c128>::value && cplx_on_mfma<FORM>(a.conjA, a.conjB, a.ext_ws)) {
         const int Me = (FORM == FORM_TN) ? 2 * a.M : a.M;
         int tbm = 0, tbn = 0;
@@ -512,7 +517,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
             }
         }
         if constexpr (std::is_same<T, double>::value) {
-            const int t64 = f64_tier(a.M, a.N, a.tile);
+            const int t64 = f64_tier(a.M, a.N, a.tile, a.K);
             if (t64 != F64_GENERIC) {
                 GemmProblemD p;
                 p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb;
