@@ -11,7 +11,14 @@ inline void dict_plan_extra(WsPlan& p, int64_t Nb, int64_t F, int64_t K) {
     p.add<T>(dict_slab_elems<T>(Nb, F, K));
     p.add<R>((size_t)2 * ((F + 63) / 64) + 512);
     p.add<R>(4);
-    atom_plan<T>(p, F, K);
+    const bool pads = dict_pads<T>(F, K);
+    const int64_t Kp = pads ? pad64(K) : K, Fp = pads ? pad64(F) : F;
+    atom_plan<T>(p, Fp, Kp);
+    if (pads) {
+        p.add<T>((size_t)Kp * Kp);
+        p.add<T>((size_t)Kp * Fp);
+        p.add<T>((size_t)Kp * Fp);
+    }
 }
 template <class T>
 inline int dict_carve_extra(dcp_handle* h, DictWs<T>& w, int64_t Nb, int64_t F, int64_t K) {
@@ -20,7 +27,15 @@ inline int dict_carve_extra(dcp_handle* h, DictWs<T>& w, int64_t Nb, int64_t F, 
     w.slabs = ws_alloc<T>(h, w.slab_count);
     w.partial = ws_alloc<R>(h, (size_t)2 * ((F + 63) / 64) + 512);
     w.scal = ws_alloc<R>(h, 4);
-    DCP_TRY(atom_carve<T>(h, w.atom, F, K));
+    const bool pads = dict_pads<T>(F, K);
+    const int64_t Kp = pads ? pad64(K) : K, Fp = pads ? pad64(F) : F;
+    DCP_TRY(atom_carve<T>(h, w.atom, Fp, Kp));
+    if (pads) {
+        w.padA = ws_alloc<T>(h, (size_t)Kp * Kp);
+        w.padB = ws_alloc<T>(h, (size_t)Kp * Fp);
+        w.padD = ws_alloc<T>(h, (size_t)Kp * Fp);
+        if (!w.padA || !w.padB || !w.padD) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
+    }
     if (!w.slabs || !w.partial || !w.scal) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
     return DCP_OK;
 }
@@ -112,14 +127,27 @@ inline int dict_update_api(dcp_handle* h, const T* stats, double beta, T* A, T* 
     if (!stats || !A || !B || !D || !Dnew || !maxdiff_dev) return fail(h, DCP_ERR_INVALID, "null pointer");
     if (F <= 0 || K <= 0) return fail(h, DCP_ERR_INVALID, "sizes must be positive");
     DCP_HIP_OK(h, hipSetDevice(h->device));
+    const bool pads = dict_pads<T>(F, K);
+    const int64_t Kp = pads ? pad64(K) : K, Fp = pads ? pad64(F) : F;
     WsPlan plan;
     plan.add<R>((size_t)2 * ((F + 63) / 64) + 512);
-    atom_plan<T>(plan, F, K);
+    atom_plan<T>(plan, Fp, Kp);
+    if (pads) {
+        plan.add<T>((size_t)Kp * Kp);
+        plan.add<T>((size_t)Kp * Fp);
+        plan.add<T>((size_t)Kp * Fp);
+    }
     DCP_TRY(ws_reserve(h, plan.total));
     ws_reset(h);
     DictWs<T> dw;
     dw.partial = ws_alloc<R>(h, (size_t)2 * ((F + 63) / 64) + 512);
-    DCP_TRY(atom_carve<T>(h, dw.atom, F, K));
+    DCP_TRY(atom_carve<T>(h, dw.atom, Fp, Kp));
+    if (pads) {
+        dw.padA = ws_alloc<T>(h, (size_t)Kp * Kp);
+        dw.padB = ws_alloc<T>(h, (size_t)Kp * Fp);
+        dw.padD = ws_alloc<T>(h, (size_t)Kp * Fp);
+        if (!dw.padA || !dw.padB || !dw.padD) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
+    }
     if (!dw.partial) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
     return dict_update<T>(h, stats, (R)beta, A, B, D, Dnew, F, K, maxdiff_dev, dw);
 }

@@ -152,7 +152,21 @@ struct DictWs {
     R* partial = nullptr;   // max|dD| partials
     R* scal = nullptr;
     AtomWs<T> atom;         // the blocked atom sweep's buffers (atom_sweep.hpp)
+    // float32 with K or F off the 64-grid: zero-padded copies [Kp,Kp], [Kp,Fp], [Kp,Fp] for the fused sweep
+    T* padA = nullptr;
+    T* padB = nullptr;
+    T* padD = nullptr;
 };
+
+// float32 dictionaries of more than one 64-atom block whose K or F is not a multiple of 64 run the fused
+// sweep on zero-padded copies: a padded atom has A_k = 0, B_k = 0, D_k = 0, so u_k = 0 / 1e-15 + 0 = 0 and it
+// stays zero without touching any other atom; padded channels are zero columns of B and D and add nothing to
+// any norm.  Exactly the sweep of the unpadded problem, at the three-launches-per-block rate.
+template <class T>
+inline bool dict_pads(int64_t F, int64_t K) {
+    return std::is_same<T, float>::value && K > 64 && !atom_fused_ok(F, K);
+}
+inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 
 template <class T>
 inline size_t dict_slab_elems(int64_t Nb, int64_t F, int64_t K) {
@@ -201,7 +215,24 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
     bool fused = false;
     if constexpr (std::is_same<T, float>::value) {
         fused = atom_fused_ok(F, K);
-        if (fused) DCP_TRY(atom_sweep_fused_f32(h, A, B, Dnew, F, K, w.atom));
+        if (fused) {
+            DCP_TRY(atom_sweep_fused_f32(h, A, B, Dnew, F, K, w.atom));
+        } else if (dict_pads<T>(F, K) && w.padA && w.padB && w.padD) {
+            const int64_t Kp = pad64(K), Fp = pad64(F);
+            DCP_HIP_OK(h, hipMemsetAsync(w.padA, 0, sizeof(T) * (size_t)Kp * Kp, st));
+            DCP_HIP_OK(h, hipMemsetAsync(w.padB, 0, sizeof(T) * (size_t)Kp * Fp, st));
+            DCP_HIP_OK(h, hipMemsetAsync(w.padD, 0, sizeof(T) * (size_t)Kp * Fp, st));
+            DCP_HIP_OK(h, hipMemcpy2DAsync(w.padA, sizeof(T) * Kp, A, sizeof(T) * K, sizeof(T) * K, K,
+                                           hipMemcpyDeviceToDevice, st));
+            DCP_HIP_OK(h, hipMemcpy2DAsync(w.padB, sizeof(T) * Fp, B, sizeof(T) * F, sizeof(T) * F, K,
+                                           hipMemcpyDeviceToDevice, st));
+            DCP_HIP_OK(h, hipMemcpy2DAsync(w.padD, sizeof(T) * Fp, Dnew, sizeof(T) * F, sizeof(T) * F, K,
+                                           hipMemcpyDeviceToDevice, st));
+            DCP_TRY(atom_sweep_fused_f32(h, w.padA, w.padB, w.padD, Fp, Kp, w.atom));
+            DCP_HIP_OK(h, hipMemcpy2DAsync(Dnew, sizeof(T) * F, w.padD, sizeof(T) * Fp, sizeof(T) * F, K,
+                                           hipMemcpyDeviceToDevice, st));
+            fused = true;
+        }
     }
     if (!fused) DCP_TRY(atom_sweep<T>(h, A, B, Dnew, F, K, w.atom));
     const int mb = grid_for((long)K * F, 256);
