@@ -235,7 +235,11 @@ inline int f64_tier(int M, int N, int tile_sel, int K = 1 << 30) {
         // few 128 x 128 tiles (the D-side products of an MU step: 256 x 4096 -> 64 tiles on 256 CUs): 64 x 64 tiles
         // put four times as many workgroups on the chip; these products are latency bound
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-        return (t128 < 96 && K <= 1024) ? F64_SQ64 : F64_128;   // (shallow reductions only)
+        if (t128 < 96 && K <= 1024) return F64_SQ64;   // (shallow reductions only)
+        // one 128-wide strip of tiles that cannot fill the chip (128 atoms, 16384 rows: 128 tiles): half-width tiles
+        if (t128 < 192 && N <= 128 && M >= 256) return F64_TALL64;
+        if (t128 < 192 && M <= 128 && N >= 256) return F64_FLAT64;
+        return F64_128;
     }
     if (N <= 32 && M >= 128) return F64_TALL32;
     if (N <= 64 && M >= 128) return F64_TALL64;
