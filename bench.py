@@ -180,10 +180,49 @@ def parity_and_cpu_baseline(torch, lib, h, Y, D0, timed_iters=3):
     return parity, base
 
 
-def secondary_configs(torch, device):
+def dict_step_parity(torch, lib, h, step_name, Y, D, alpha=0.1, lasso_iter=10, lasso_tol=1e-5):
+    """ONE dictionary-learning minibatch step (dictionary_learning.py:135-164) from the reference's
+    starting state (x = 1, A = B = 0, count = 0) through dcp_dict_step_* and through the NumPy oracle
+    (oracle.dictionary_learning.minibatch_step: lasso.solve_fastpath ista + A, B + sequential atom
+    sweep) on the host copy of the very arrays the step is timed on: identical LASSO iteration count,
+    x and D_new within 2e-4 of the largest entry (single precision)."""
+    import numpy as np
+    from decomp_amd import _arrays, _hip
+    from oracle import dictionary_learning as odl
+    MB, F = Y.shape
+    K = D.shape[0]
+    x = torch.ones((MB, K), device=Y.device, dtype=D.dtype)
+    A = torch.zeros((K, K), device=Y.device, dtype=D.dtype)
+    B = torch.zeros((K, F), device=Y.device, dtype=D.dtype)
+    Dn = torch.empty_like(D)
+    md, lit = ctypes.c_double(0), ctypes.c_int(0)
+    _hip.check(h, getattr(lib, step_name)(h, _arrays.ptr(Y), _arrays.ptr(x), _arrays.ptr(D), _arrays.ptr(Dn),
+                                          _arrays.ptr(A), _arrays.ptr(B), MB, F, K, (1.0 - MB) / 1.0, alpha,
+                                          _hip.LASSO_ISTA, lasso_iter, lasso_tol, ctypes.byref(md),
+                                          ctypes.byref(lit)), step_name + ' (parity)')
+    gx, gD = x.cpu().numpy(), Dn.cpu().numpy()
+    y, d = Y.cpu().numpy(), D.cpu().numpy()
+    t0 = time.perf_counter()
+    it2, ox, _, _, oD, odiff = odl.minibatch_step(y, np.ones((MB, K), y.dtype), d, np.zeros((K, K), y.dtype),
+                                                  np.zeros((K, F), y.dtype), 0, MB, alpha, 'ista', lasso_iter,
+                                                  lasso_tol)
+    cpu_s = time.perf_counter() - t0
+    ex = float(np.max(np.abs(gx - ox))) / float(np.max(np.abs(ox)))
+    eD = float(np.max(np.abs(gD - oD))) / float(np.max(np.abs(oD)))
+    tol = 2.0e-4
+    return {'metric': 'one minibatch step from x=1, A=B=0: HIP vs NumPy oracle (oracle.dictionary_learning.'
+                      'minibatch_step), max|diff| / max|oracle|',
+            'lasso_it_hip': lit.value, 'lasso_it_oracle': int(it2), 'x_rel_err': ex, 'D_rel_err': eD,
+            'maxdiff_hip': md.value, 'maxdiff_oracle': odiff, 'code_density': float((ox != 0).mean()),
+            'tolerance': tol, 'oracle_s_per_step': cpu_s,
+            'pass': bool(lit.value == it2 and ex <= tol and eD <= tol)}
+
+
+def secondary_configs(torch, device, with_oracle=False):
     """The other BASELINE configs at their one-GPU shapes, measured live in a few seconds each (they
     are parity-test cases, not the headline; reported so that their numbers in DESIGN.md have a
-    driver-side record).  Synthetic data of SURVEY 8d's recipes."""
+    driver-side record).  Synthetic data of SURVEY 8d's recipes.  with_oracle: also check one dictionary
+    step of configs[2] / configs[4] against the NumPy oracle at the timed shape (dict_step_parity)."""
     from decomp_amd import _arrays, _hip
     out = {}
     g = torch.Generator(device=device)
@@ -220,6 +259,7 @@ def secondary_configs(torch, device):
     D_new = torch.empty_like(D)
     lib, h = _arrays.lib_handle(D)
     md, lit = ctypes.c_double(0), ctypes.c_int(0)
+    dl_parity = dict_step_parity(torch, lib, h, 'dcp_dict_step_f32', Y, D) if with_oracle else None
     state = {'D': D, 'Dn': D_new, 'count': 0}
 
     def dl_step(method=_hip.LASSO_ISTA):
@@ -232,6 +272,8 @@ def secondary_configs(torch, device):
         state['count'] += 1
     out['dictionary_step_ms'] = {'workload': 'configs[2] minibatch 8192x4096 k=512 ista x10 fp32',
                                  'value': round(ms_of(dl_step, 6), 4)}
+    if dl_parity is not None:
+        out['dictionary_step_ms']['parity'] = dl_parity
     # the same step with the reference's DEFAULT inner solver (dictionary_learning.py:14, lasso_method='cd'),
     # codes carried over from the previous visit of the minibatch as in the reference's epochs
     out['dictionary_step_cd_ms'] = {'workload': "configs[2] minibatch 8192x4096 k=512 cd x10 fp32",
@@ -315,6 +357,7 @@ def secondary_configs(torch, device):
     xc = torch.ones((MB, K), device=device, dtype=torch.complex64)
     Ac = torch.zeros((K, K), device=device, dtype=torch.complex64)
     Bc = torch.zeros((K, F), device=device, dtype=torch.complex64)
+    c_parity = dict_step_parity(torch, lib, h, 'dcp_dict_step_c64', Yc, Dc) if with_oracle else None
     cstate = {'D': Dc, 'Dn': torch.empty_like(Dc), 'count': 0}
 
     def dl_c64():
@@ -327,6 +370,8 @@ def secondary_configs(torch, device):
         cstate['count'] += 1
     out['complex_dictionary_step_ms'] = {'workload': 'configs[4] minibatch 8192x8192 complex64 k=512 ista x10',
                                          'value': round(ms_of(dl_c64, 4), 4)}
+    if c_parity is not None:
+        out['complex_dictionary_step_ms']['parity'] = c_parity
     return out
 
 
@@ -496,7 +541,7 @@ def main():
             try:
                 del Y
                 torch.cuda.empty_cache()
-                out['secondary'] = secondary_configs(torch, device)
+                out['secondary'] = secondary_configs(torch, device, with_oracle=not args.no_cpu_baseline)
                 sh = out['secondary'].get('shard_8192_rows_ms_per_iter')
                 if sh:      # the full problem's step against one of its eight shards (before the all-reduce)
                     sh['compute_side_speedup_at_8_gpus'] = round(ms_step / sh['value'], 2)
@@ -505,6 +550,11 @@ def main():
         print(json.dumps(out))
         if 'parity' in out and not out['parity']['pass']:
             raise SystemExit('parity gate FAILED: %r' % (out['parity'],))
+        for key in ('dictionary_step_ms', 'complex_dictionary_step_ms'):
+            par = (out.get('secondary') or {}).get(key, {})
+            par = par.get('parity') if isinstance(par, dict) else None
+            if par is not None and not par['pass']:
+                raise SystemExit('%s parity gate FAILED: %r' % (key, par))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -35,6 +35,25 @@ def atom_sweep_mask(D, D_prev, A, B):
     return D_new
 
 
+def minibatch_step(y_mb, x_mb, D, A, B, count, minibatch, alpha, lasso_method,
+                   lasso_iter, lasso_tol):
+    """One unmasked minibatch step, dictionary_learning.py:137-161: LASSO on the
+    minibatch (x_mb is the warm start and is NOT modified here), the running
+    statistics A <- beta A + x^H x, B <- beta B + x^H y, the sequential atom
+    sweep.  Returns (lasso_it, x_new, A, B, D_new, max|D - D_new|)."""
+    it2, x_new = lasso.solve_fastpath(                           # :137-139
+        y_mb, D, alpha, x=x_mb, tol=lasso_tol, maxiter=lasso_iter,
+        method=lasso_method, mask=None)
+    theta = count * minibatch + 1.0                              # :143
+    beta = (theta - minibatch) / theta                           # :144 (QUIRK: < 0 at count 0)
+    xH = np.conj(x_new.T) if y_mb.dtype.kind == 'c' else x_new.T  # :147-149
+    A = beta * A + np.dot(xH, x_new)                             # :151
+    B = beta * B + np.dot(xH, y_mb)                              # :152
+    D_new = atom_sweep(D, A, B)                                  # :154-159
+    diff = float(np.max(np.abs(D - D_new)))                      # :161
+    return it2, x_new, A, B, D_new, diff
+
+
 def solve(y, D, alpha, x=None, tol=1.0e-3, minibatch=None, maxiter=1000,
           lasso_method='cd', lasso_iter=10, lasso_tol=1.0e-5, mask=None,
           random_seed=None, trace=None):

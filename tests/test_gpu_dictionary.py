@@ -91,7 +91,11 @@ def test_golden_single_precision_and_wide(name):
                                     # ragged channel counts (bounds-checked products), complex64 on the
                                     # planar-rows products with 2, 3 and 4 blocks of 32 atoms
                                     ('float32', 128, 100), ('complex64', 96, 130), ('complex64', 64, 256),
-                                    ('complex64', 128, 67), ('float64', 96, 130)])
+                                    ('complex64', 128, 67), ('float64', 96, 130),
+                                    # the widths the dictionary step is TIMED at (BASELINE configs[2] / [4]):
+                                    # 8 fused float32 blocks over F = 4096, 16 complex blocks of 32 atoms
+                                    ('float32', 512, 4096), ('complex64', 512, 8192), ('float64', 512, 1024),
+                                    ('complex128', 512, 512)])
 def test_atom_sweep_direct_against_oracle(dt, K, F):
     """dcp_dict_update_* alone (A/B accumulation + the blocked Gauss-Seidel atom sweep + max|dD|)
     against oracle.dictionary_learning.atom_sweep (dictionary_learning.py:154-159) for dictionaries
@@ -104,7 +108,7 @@ def test_atom_sweep_direct_against_oracle(dt, K, F):
     from oracle.common import l2_strict
     rng = np.random.RandomState(K)
     cplx = dt.startswith('complex')
-    Nb = 300
+    Nb = 300 if K <= 256 else 1200
 
     def randn(*s):
         return (rng.randn(*s) + 1j * rng.randn(*s)) if cplx else rng.randn(*s)

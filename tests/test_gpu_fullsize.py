@@ -212,6 +212,120 @@ def _dl_objective(Y, x, D, alpha):
     return float((0.5 / Y.shape[1] * torch.sum(torch.abs(r) ** 2) + alpha * torch.sum(torch.abs(x))) / Y.shape[0])
 
 
+def _dl_host_data(rows, F_, K_, cplx, seed):
+    """SURVEY 8(d) C3 / C5 recipe on the HOST with np.random.RandomState (the data the oracle and the
+    HIP path both start from): Dt = randn(K, F), xt = 30 randn . Bernoulli(0.05), Y = xt Dt + 0.1 randn,
+    D0 = Dt + 0.2 randn; complex: randn + 1j randn, complex64."""
+    rng = np.random.RandomState(seed)
+    dt = np.complex64 if cplx else np.float32
+
+    def randn(*s):
+        r = rng.randn(*s).astype(np.float32)
+        return (r + 1j * rng.randn(*s).astype(np.float32)).astype(dt) if cplx else r
+    Dt = randn(K_, F_)
+    xt = (30.0 * randn(rows, K_) * (rng.uniform(size=(rows, K_)) < 0.05)).astype(dt)
+    Y = (xt @ Dt + np.float32(0.1) * randn(rows, F_)).astype(dt)
+    D0 = (Dt + np.float32(0.2) * randn(K_, F_)).astype(dt)
+    return Y, D0
+
+
+def _hip_dict_steps(Y, D0, x0, alpha, method_code, lasso_iter, lasso_tol, n_steps):
+    """n_steps calls of dcp_dict_step_* on the same minibatch (as the reference's epochs revisit it):
+    returns per step (lasso_it, x, A, B, D_new, maxdiff) as host arrays."""
+    import ctypes
+    import torch
+    from decomp_amd import _arrays, _hip
+    Yd = torch.from_numpy(Y).cuda()
+    D = torch.from_numpy(D0).cuda()
+    _arrays.l2_normalize_(D, strict=True)                    # dictionary_learning.py:126
+    x = torch.from_numpy(x0).cuda()
+    Nb, F_ = Y.shape
+    K_ = D0.shape[0]
+    A = torch.zeros((K_, K_), dtype=D.dtype, device='cuda')
+    B = torch.zeros((K_, F_), dtype=D.dtype, device='cuda')
+    Dn = torch.empty_like(D)
+    lib, h = _arrays.lib_handle(D)
+    step = getattr(lib, 'dcp_dict_step_' + _arrays.suffix(D))
+    out = []
+    md, lit = ctypes.c_double(0), ctypes.c_int(0)
+    for count in range(n_steps):
+        theta = count * Nb + 1.0
+        _hip.check(h, step(h, _arrays.ptr(Yd), _arrays.ptr(x), _arrays.ptr(D), _arrays.ptr(Dn), _arrays.ptr(A),
+                           _arrays.ptr(B), Nb, F_, K_, (theta - Nb) / theta, alpha, method_code, lasso_iter,
+                           lasso_tol, ctypes.byref(md), ctypes.byref(lit)), 'dcp_dict_step')
+        out.append((lit.value, x.cpu().numpy(), A.cpu().numpy(), B.cpu().numpy(), Dn.cpu().numpy(), md.value))
+        D, Dn = Dn, D
+    return out
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b))) / max(float(np.max(np.abs(b))), 1e-30)
+
+
+@pytest.mark.parametrize('cplx,F_', [(False, 4096), (True, 8192)])
+def test_dictionary_step_oracle_parity_ista_at_timed_shape(cplx, F_):
+    """The dictionary step exactly as bench.py times it -- one minibatch of BASELINE configs[2]
+    (8192 x 4096, k = 512, float32) / configs[4] (8192 x 8192, k = 512, complex64), alpha = 0.1, ista x 10
+    -- against the NumPy oracle on the same host data, two consecutive steps (the second with beta > 0,
+    non-zero A, B and warm codes): oracle.dictionary_learning.minibatch_step = lasso.solve_fastpath
+    (lasso.py:97-189, 274-297) + A, B accumulation (dictionary_learning.py:143-152) + the sequential atom
+    sweep (:154-159).  Identical LASSO iteration count; x, A, B, D_new within 2e-4 of the largest entry
+    (single precision, K = 512 dependent atom updates)."""
+    from decomp_amd import _hip
+    from oracle import dictionary_learning as odl
+    from oracle.common import l2_strict
+    rows, K_ = 8192, 512
+    Y, D0 = _dl_host_data(rows, F_, K_, cplx, seed=3 if cplx else 2)
+    x0 = np.ones((rows, K_), dtype=Y.dtype)                  # dictionary_learning.py:58-59
+    hip = _hip_dict_steps(Y, D0, x0, 0.1, _hip.LASSO_ISTA, 10, 1e-5, 2)
+    D = l2_strict(D0)
+    A = np.zeros((K_, K_), Y.dtype)
+    B = np.zeros((K_, F_), Y.dtype)
+    x = x0
+    for count in range(2):
+        it2, x, A, B, D_new, diff = odl.minibatch_step(Y, x, D, A, B, count, rows, 0.1, 'ista', 10, 1e-5)
+        g_it, gx, gA, gB, gD, gdiff = hip[count]
+        assert g_it == it2, (count, g_it, it2)
+        dens = float((x != 0).mean())
+        assert 0.005 < dens < 0.3, dens                      # a sparse, non-empty code (SURVEY 8d)
+        assert _rel(gx, x) < 2e-4, (count, 'x', _rel(gx, x))
+        assert _rel(gA, A) < 2e-4, (count, 'A', _rel(gA, A))
+        assert _rel(gB, B) < 2e-4, (count, 'B', _rel(gB, B))
+        assert _rel(gD, D_new) < 2e-4, (count, 'D', _rel(gD, D_new))
+        assert abs(gdiff - diff) <= 2e-4 * max(1.0, diff), (count, gdiff, diff)
+        D = D_new
+
+
+def test_dictionary_step_oracle_parity_cd_at_timed_shape():
+    """The same step with the reference's DEFAULT inner solver (lasso_method = 'cd',
+    dictionary_learning.py:14).  The reference's sweep recomputes x.A for every coordinate
+    (lasso.py:539-551: 2 N K F flops per coordinate, 1.8e14 for this minibatch), so the oracle runs
+    stage-wise: (1) its as-written coordinate descent on 64 rows spread over the minibatch (rows are
+    independent given D; from x = 1 the all-rows stop test at sweep 0 cannot fire, so both run the full 10
+    sweeps) pins the codes; (2) A, B and the sequential atom sweep of the oracle, fed with the HIP path's
+    codes, pin the D side at K = 512, F = 4096."""
+    from decomp_amd import _hip
+    from oracle import dictionary_learning as odl, lasso as olasso
+    from oracle.common import l2_strict
+    rows, F_, K_ = 8192, 4096, 512
+    Y, D0 = _dl_host_data(rows, F_, K_, False, seed=2)
+    x0 = np.ones((rows, K_), dtype=np.float32)
+    (g_it, gx, gA, gB, gD, gdiff), = _hip_dict_steps(Y, D0, x0, 0.1, _hip.LASSO_CD, 10, 1e-5, 1)
+    D = l2_strict(D0)
+    sel = np.arange(0, rows, rows // 64)
+    it2, xs = olasso.solve_fastpath(Y[sel], D, 0.1, x=x0[sel].copy(), tol=1e-5, maxiter=10, method='cd')
+    assert g_it == it2 == 9
+    assert 0.005 < float((xs != 0).mean()) < 0.3
+    assert _rel(gx[sel], xs) < 2e-4, _rel(gx[sel], xs)
+    beta = (1.0 - rows) / 1.0
+    A = beta * np.zeros((K_, K_), np.float32) + gx.T @ gx
+    B = beta * np.zeros((K_, F_), np.float32) + gx.T @ Y
+    D_new = odl.atom_sweep(D, A, B)
+    assert _rel(gA, A) < 2e-4 and _rel(gB, B) < 2e-4
+    assert _rel(gD, D_new) < 2e-4, _rel(gD, D_new)
+    assert abs(gdiff - float(np.max(np.abs(D - D_new)))) <= 2e-4
+
+
 @pytest.mark.parametrize('lasso_method', ['ista', 'cd'])
 def test_c3_dictionary_learning_properties(lasso_method):
     """BASELINE configs[2] at its full shape (Y 65536 x 4096, k = 512, alpha = 0.1, fp32, minibatch 8192),
@@ -238,8 +352,9 @@ def test_c3_dictionary_learning_properties(lasso_method):
 
 def test_c5_complex_dictionary_step_properties():
     """BASELINE configs[4] at one GPU's minibatch shape (8192 x 8192 complex64, k = 512): one epoch over
-    two minibatches; finite, sparse, deterministic, and the complex64 result agrees with the same run
-    in complex128 (fp64 MFMA core) to single precision."""
+    two minibatches; finite, sparse, deterministic.  SECONDARY to
+    test_dictionary_step_oracle_parity_ista_at_timed_shape (the NumPy oracle at this shape): the
+    complex64 result also agrees with the same run in complex128 (fp64 MFMA core) to single precision."""
     import torch
     import decomp_amd
     rows, F_, K_ = 2 * 8192, 8192, 512

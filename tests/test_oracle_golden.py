@@ -243,3 +243,39 @@ def test_nmf_minibatch_all_cases(golden_dir):
             assert it == int(g[name + '/it']), name
             assert _close(D, g[name + '/D'], tol), name
             assert _close(x, g[name + '/x'], tol), name
+
+
+def test_dictionary_minibatch_step_equals_solve():
+    """oracle.dictionary_learning.minibatch_step (the one-step restatement the full-shape GPU gates and
+    bench.py use) reproduces the per-step trace of oracle.dictionary_learning.solve -- which is pinned to the
+    reference's fixtures above -- when driven with the same shuffles."""
+    from oracle import dictionary_learning as odl
+    from oracle.common import l2_strict
+    rng = np.random.RandomState(5)
+    for cplx in (False, True):
+        y = rng.randn(60, 7) + (1j * rng.randn(60, 7) if cplx else 0)
+        D0 = rng.randn(4, 7) + (1j * rng.randn(4, 7) if cplx else 0)
+        trace = []
+        odl.solve(y.copy(), D0.copy(), 0.1, tol=0.0, minibatch=20, maxiter=3, lasso_method='ista',
+                  lasso_iter=10, lasso_tol=1e-5, random_seed=1, trace=trace)
+        # replay: same RandomState stream, cumulative shuffles (dictionary_learning.py:131-133)
+        r2 = np.random.RandomState(1)
+        index = np.arange(60)
+        ys, xs = y.copy(), np.ones((60, 4), dtype=D0.dtype)
+        D = l2_strict(D0)
+        A = np.zeros((4, 4), y.dtype)
+        B = np.zeros((4, 7), y.dtype)
+        count = 0
+        for _ in range(2):
+            r2.shuffle(index)
+            ys, xs = ys[index], xs[index]
+            for b in range(3):
+                sl = slice(20 * b, 20 * b + 20)
+                it2, xn, A, B, D, diff = odl.minibatch_step(ys[sl], xs[sl], D, A, B, count, 20, 0.1,
+                                                            'ista', 10, 1e-5)
+                xs[sl] = xn
+                t = trace[count]
+                assert it2 == t['lasso_it']
+                assert np.array_equal(A, t['A']) and np.array_equal(B, t['B']) and np.array_equal(D, t['D'])
+                assert diff == t['maxdiff']
+                count += 1
