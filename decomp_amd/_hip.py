@@ -86,6 +86,10 @@ SIGNATURES = {
     'dcp_dict_mask_step_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
     'dcp_nmf_grads_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp]),
     'dcp_nmf_grads_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp]),
+    'dcp_nmf_grad_x_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_vp, _c_vp]),
+    'dcp_nmf_grad_x_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_int, _c_vp, _c_vp]),
+    'dcp_nmf_gauss_logp_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _P(_c_f64)]),
+    'dcp_nmf_gauss_logp_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _P(_c_f64)]),
     'dcp_nmf_apply_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_f64, _c_vp, _c_i64, _c_i64, _P(_c_f64)]),
     'dcp_nmf_apply_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_f64, _c_vp, _c_i64, _c_i64, _P(_c_f64)]),
     'dcp_axpby_f32': (_c_int, [_c_vp, _c_i64, _c_f64, _c_vp, _c_f64, _c_vp]),

@@ -698,6 +698,9 @@ inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi&
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
     if (p.B2 == nullptr) p.n_b1 = p.N;
     if (p.A2 == nullptr) p.m_a1 = p.M;
+    // Stacked A: the second segment's tiles start at OUTPUT row tiles_m1 * BM, which is m_a1 only when the
+    // first segment is a whole number of tiles (the bounds-checked instantiation does not re-map rows).
+    if (p.A2 != nullptr && (p.m_a1 % BM) != 0) return hipErrorInvalidValue;
     p.tiles_m1 = (p.m_a1 + BM - 1) / BM;
     p.tiles_m = p.tiles_m1 + (p.M - p.m_a1 + BM - 1) / BM;
     p.tiles_n1 = (p.n_b1 + BN - 1) / BN;

@@ -13,7 +13,13 @@
 struct dcp_handle {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t stream_switch = nullptr;   // orders the shared arena across dcp_set_stream changes
+    // The workspace arena is shared by every arena-using call on this handle.  arena_stream is the stream
+    // the last such call enqueued on; when the next one runs on a different stream (dcp_set_stream in
+    // between), ws_reserve makes the new stream wait for the old one with this event -- calls that never
+    // touch the arena (the row movers of the out-of-core feed) are not ordered against anything.
+    hipEvent_t stream_switch = nullptr;
+    hipStream_t arena_stream = nullptr;
+    bool arena_stream_set = false;
     // Side stream for work that can run BESIDE a kernel that leaves most of the chip idle (the atom
     // sweep's look-ahead product next to the one-workgroup recursion); created on first use and
     // ordered against the main stream with events only (side_after_main / main_after_side).
@@ -117,9 +123,31 @@ inline void ws_reset(dcp_handle* h) {
     h->arena_used = 0;
 }
 
+// The arena's previous user may still be running on another stream: the current stream waits for it
+// (an event, no host sync).  If the event cannot be recorded -- the previous stream was destroyed by
+// the caller, which decomp_hip.h forbids while work of this handle may be pending on it -- fall back to
+// a device synchronisation rather than fail or race.
+inline void ws_order_streams(dcp_handle* h) {
+    if (h->arena_stream_set && h->arena_stream != h->stream && h->arena != nullptr) {
+        bool ok = false;
+        if (h->stream_switch == nullptr)
+            (void)hipEventCreateWithFlags(&h->stream_switch, hipEventDisableTiming);
+        if (h->stream_switch != nullptr && hipEventRecord(h->stream_switch, h->arena_stream) == hipSuccess &&
+            hipStreamWaitEvent(h->stream, h->stream_switch, 0) == hipSuccess)
+            ok = true;
+        if (!ok) {
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
+        }
+    }
+    h->arena_stream = h->stream;
+    h->arena_stream_set = true;
+}
+
 // Reserve the total workspace for a call up front (so no allocation happens
-// between kernels).  Returns DCP_OK or an error code.
+// between kernels).  Returns DCP_OK or an error code.  Every arena-using entry point calls this first.
 inline int ws_reserve(dcp_handle* h, size_t bytes) {
+    ws_order_streams(h);
     if (bytes <= h->arena_bytes) return DCP_OK;
     if (h->arena) {
         hipError_t e = hipStreamSynchronize(h->stream);

@@ -109,6 +109,34 @@ __global__ void __launch_bounds__(256) bcast_rows_kernel(const T* __restrict__ v
     }
 }
 
+// out[r, c] = v[c] for r in [0, rows)  (a per-column value repeated on every row)
+template <class T>
+__global__ void __launch_bounds__(256) bcast_cols_kernel(const T* __restrict__ v, long rows, long cols,
+                                                         T* __restrict__ out) {
+    const long count = rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < count; i += (long)gridDim.x * 256L)
+        out[i] = v[i % cols];
+}
+
+// Gaussian.logp (grads.py:127-135), summand (-0.5 ((y - f) / scale)^2 - log(scale) - pi / 2) [* mask] with
+// d = y - f given; double accumulation -> partial[block].
+template <class T>
+__global__ void __launch_bounds__(256) gauss_logp_partial_kernel(const T* __restrict__ d,
+                                                                 const T* __restrict__ mask, long n,
+                                                                 double inv_scale, double cst,
+                                                                 double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double c = 0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        const double z = (double)d[i] * inv_scale;
+        double t = -0.5 * z * z - cst;
+        if (mask != nullptr) t *= (double)mask[i];
+        c += t;
+    }
+    double t = block_sum_256(c, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
 // out = a o b (elementwise; b real "mask" of the same shape, or broadcast along rows when
 // b_row_stride == 0).
 template <class T>

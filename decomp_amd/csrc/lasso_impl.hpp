@@ -376,6 +376,93 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
     if (__ballot(viol) != 0ull && lane == 0) *flag = 1;
 }
 
+// The same sweep for dictionaries wider than the register form's 2048 atoms (64 lanes x 32 slots): the
+// row's x and g stay in global memory (their own row of X / G: L2-resident, touched by this wave only,
+// every lane only ever reads and writes ITS columns c = lane (mod 64), so program order is the only
+// ordering needed), one 64-column slot at a time lives in registers while its coordinates are swept, and
+// an applied step updates the other slots' g by read-modify-write, eight slots in flight.  Arithmetic
+// and update order are those of cd_gram_kernel (identical results where both apply).
+template <class T, int PROX>
+__global__ void __launch_bounds__(256) cd_gram_wide_kernel(T* __restrict__ X, T* __restrict__ G,
+                                                           const T* __restrict__ AAt,
+                                                           const real_t<T>* __restrict__ alphak,
+                                                           const real_t<T>* __restrict__ tolk, long rows,
+                                                           int K, int nsweeps, int check_last,
+                                                           int* __restrict__ flag) {
+    typedef real_t<T> R;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int M = (K + 63) / 64;
+    T* xrow = X + row * K;
+    T* grow = G + row * K;
+    bool viol = false;
+    for (int s = 0; s < nsweeps; ++s) {
+        const bool check = check_last && (s == nsweeps - 1);
+        for (int m = 0; m < M; ++m) {
+            const int c0 = lane + 64 * m;
+            const bool ok = c0 < K;
+            const int cc = ok ? c0 : 0;
+            const T xv = xrow[cc], gv = grow[cc], av = AAt[(long)cc * K + cc];
+            const R alv = alphak[cc], tlv = tolk[cc];
+            T x = ok ? xv : zero_of<T>();
+            T g = ok ? gv : zero_of<T>();
+            const T akk = ok ? av : zero_of<T>();
+            const R al = ok ? alv : R(0);
+            const R tl = ok ? tlv : R(1);
+            const int kend = min(64, K - 64 * m);
+            int cursor = 0;
+            while (true) {
+                const T z = add(g, mul(x, akk));
+                const T xn = prox_apply<PROX>(z, al);
+                const T d = sub(xn, x);
+                const bool moves = (lane >= cursor) && (lane < kend) && (abs2(d) != R(0));
+                const unsigned long long mask = __ballot(moves);
+                if (mask == 0ull) {
+                    if (check && lane >= cursor && lane < kend && !((R(0) - tl) < R(0))) viol = true;
+                    break;
+                }
+                const int kk = __ffsll((long long)mask) - 1;
+                if (check && lane >= cursor && lane < kk && !((R(0) - tl) < R(0))) viol = true;
+                T dk;
+                if constexpr (scalar_traits<T>::is_complex) {
+                    dk.re = __shfl(d.re, kk, 64);
+                    dk.im = __shfl(d.im, kk, 64);
+                } else {
+                    dk = __shfl(d, kk, 64);
+                }
+                if (lane == kk) {
+                    x = xn;
+                    if (check && !((absval(d) - tl) < R(0))) viol = true;
+                }
+                const T* arow = AAt + (long)(64 * m + kk) * K;
+                g = ok ? sub(g, mul(dk, arow[cc])) : g;          // this slot: the register copy
+                for (int m0 = 0; m0 < M; m0 += 8) {               // the other slots: in memory
+                    T ar[8], gg[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = lane + 64 * (m0 + u);
+                        const int ci = (m0 + u < M && c < K) ? c : 0;
+                        ar[u] = arow[ci];
+                        gg[u] = grow[ci];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = lane + 64 * (m0 + u);
+                        if (m0 + u < M && m0 + u != m && c < K) grow[c] = sub(gg[u], mul(dk, ar[u]));
+                    }
+                }
+                cursor = kk + 1;
+            }
+            if (ok) {
+                xrow[c0] = x;
+                grow[c0] = g;
+            }
+        }
+    }
+    if (__ballot(viol) != 0ull && lane == 0) *flag = 1;
+}
+
 // Masked coordinate descent, as written in lasso.py:555-583: with r = (y - x.A) o M kept in
 // memory,  x_k <- S(r . conj(A_k) + x_k (A_k . conj(A_k)), alpha_nk);  r -= dx (A_k o M).
 // One workgroup per row; F-length dot products by block reduction.  (Parity path for
@@ -439,6 +526,17 @@ template <class R>
 __global__ void __launch_bounds__(256) square_vec_kernel(const R* __restrict__ v, long n, R* __restrict__ out) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
         out[i] = v[i] * v[i];
+}
+
+// Widest dictionary the register form of the coordinate descent takes (64 lanes x 32 slots).  The
+// environment variable DCP_CD_REGISTER_LIMIT (tests only) lowers it, so that the memory-resident form
+// can be checked bit for bit against the register form on the same problem.
+inline int cd_register_limit() {
+    const char* e = getenv("DCP_CD_REGISTER_LIMIT");
+    int v = e ? atoi(e) : 2048;
+    if (v < 1024) v = 1024;     // the launch ladder above 1024 is the only place it is consulted
+    if (v > 2048) v = 2048;
+    return v;
 }
 
 // ---- the solver ----------------------------------------------------------------------------------
@@ -609,11 +707,6 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
     typedef real_t<T> R;
     hipStream_t st = h->stream;
     const int N = (int)N64, F = (int)F64, K = (int)K64;
-    // The Gram-form coordinate descent keeps a row's K coefficients in one wave's registers
-    // (64 lanes x 32 slots).  Checked before anything is enqueued; parallel_cd is included
-    // because it falls back to cd when p <= 1 (lasso.py:468-470).
-    if ((method == DCP_LASSO_CD || method == DCP_LASSO_PARALLEL_CD) && mask_ndim != 2 && K > 64 * 32)
-        return fail(h, DCP_ERR_UNSUPPORTED, "cd: n_features > 2048 not supported");
     void* hostv = nullptr;
     DCP_TRY(host_scratch(h, 64, &hostv));
     int* host_flag = reinterpret_cast<int*>(hostv);
@@ -780,8 +873,19 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         // ---------------- ADMM with a 2-D mask: one K x K system per row (lasso.py:621-657) --------
         typedef work_t<T> TW;
         const R rho = (R)extra.rho;
-        if ((size_t)2 * K * sizeof(TW) > 65536)
+        // dynamic LDS of the two per-row kernels: pivot row + column (2 K work elements) and V (K elements);
+        // beyond the default 64 KiB the per-function cap is raised, up to the CU's 160 KiB (K <= 10240 real,
+        // 5120 complex -- where ONE row's K x K system is already 0.8 GB; the reference, lasso.py:620-657,
+        // holds the same N K^2 array)
+        const size_t gj_lds = (size_t)2 * K * sizeof(TW), step_lds = (size_t)K * sizeof(T);
+        if (gj_lds > 160 * 1024)
             return fail(h, DCP_ERR_UNSUPPORTED, "masked admm: n_features too large for the per-row inverse");
+        if (gj_lds > 65536)
+            DCP_HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gj_batched_kernel<TW>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)gj_lds));
+        if (step_lds > 65536)
+            DCP_HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&admm_mask_step_kernel<T, PROX>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
         hipLaunchKernelGGL((admm_mask_system_kernel<T>), dim3(N), dim3(256), 0, st, (const T*)w.An, mask,
                            K, (long)F, extra.rho, w.inv_a);
         DCP_LAUNCH_OK(h, hipGetLastError());
@@ -830,12 +934,18 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
     hipLaunchKernelGGL((cd_gram_kernel<T, PROX, MM>), dim3(grid), dim3(256), 0, st, xcur, w.G,       \
                        (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,        \
                        check_last, w.flag)
+            // (the register form holds a row's K coefficients in one wave: 64 lanes x up to 32 slots;
+            //  wider dictionaries take the memory-resident form -- the reference has no limit, lasso.py:526-552)
             if (K <= 64) DCP_CD_LAUNCH(1);
             else if (K <= 128) DCP_CD_LAUNCH(2);
             else if (K <= 256) DCP_CD_LAUNCH(4);
             else if (K <= 512) DCP_CD_LAUNCH(8);
             else if (K <= 1024) DCP_CD_LAUNCH(16);
-            else DCP_CD_LAUNCH(32);
+            else if (K <= cd_register_limit()) DCP_CD_LAUNCH(32);
+            else
+                hipLaunchKernelGGL((cd_gram_wide_kernel<T, PROX>), dim3(grid), dim3(256), 0, st, xcur, w.G,
+                                   (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,
+                                   check_last, w.flag);
 #undef DCP_CD_LAUNCH
             DCP_LAUNCH_OK(h, hipGetLastError());
             sweep = last + 1;

@@ -303,6 +303,63 @@ int nmf_grads_api(dcp_handle* h, const T* Y, const T* mask, T* X, const T* D, in
     return DCP_OK;
 }
 
+// Gaussian / Poisson.grad_x (grads.py:108-115, 143-150): the two parts of the x gradient, [N, K] each.
+template <class T>
+int nmf_grad_x_api(dcp_handle* h, const T* Y, const T* mask, const T* X, const T* D, int64_t N, int64_t F,
+                   int64_t K, int lik, T* grad_pos, T* grad_neg) {
+    DCP_TRY(check_nmf_args(h, Y, X, D, N, F, K, lik));
+    if (!grad_pos || !grad_neg) return fail(h, DCP_ERR_INVALID, "null gradient pointer");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    const bool masked = mask != nullptr;
+    NmfShape<T> s{N, F, K, lik, masked};
+    WsPlan plan;
+    nmf_plan_stats(plan, s, masked);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    NmfStatsWs<T> ws;
+    DCP_TRY(nmf_carve_stats(h, ws, s, masked));
+    const T* Ypre = Y;
+    if (masked) {
+        hipLaunchKernelGGL((mul_mask_kernel<T>), dim3(grid_for(N * F)), dim3(256), 0, h->stream, Y, mask,
+                           (long)N, (long)F, (long)F, ws.Ym);
+        DCP_HIP_OK(h, hipGetLastError());
+        Ypre = ws.Ym;
+    }
+    return nmf_grad_x<T>(h, Ypre, mask, X, D, s, grad_pos, grad_neg, ws);
+}
+
+// Gaussian.logp (grads.py:127-135): sum((-0.5 ((y - x d) / scale)^2 - log(scale) - pi * 0.5) [* mask]).
+template <class T>
+int nmf_gauss_logp_api(dcp_handle* h, const T* Y, const T* mask, const T* X, const T* D, int64_t N,
+                       int64_t F, int64_t K, double scale, double* out) {
+    DCP_TRY(check_nmf_args(h, Y, X, D, N, F, K, DCP_LIK_L2));
+    if (!out) return fail(h, DCP_ERR_INVALID, "out is null");
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    const int blocks = 1024;
+    WsPlan plan;
+    plan.add<T>((size_t)N * F);
+    plan.add<double>(blocks);
+    DCP_TRY(ws_reserve(h, plan.total));
+    ws_reset(h);
+    T* tmp = ws_alloc<T>(h, (size_t)N * F);
+    double* part = ws_alloc<double>(h, blocks);
+    if (!tmp || !part) return fail(h, DCP_ERR_INTERNAL, "workspace plan mismatch");
+    void* hostv = nullptr;
+    DCP_TRY(host_scratch(h, sizeof(double) * blocks, &hostv));
+    GemmArgs<T> a;
+    a.A = X; a.lda = K; a.B = D; a.ldb = F; a.M = (int)N; a.N = (int)F; a.K = (int)K;
+    DCP_LAUNCH_OK(h, (gemm<FORM_NN>(h->stream, a, EpiResidual<T>{Y, F, nullptr, 0, tmp, F})));   // d = y - x D
+    hipLaunchKernelGGL((gauss_logp_partial_kernel<T>), dim3(blocks), dim3(256), 0, h->stream, (const T*)tmp,
+                       mask, (long)N * F, 1.0 / scale, log(scale) + 3.14159265358979323846 * 0.5, part);
+    DCP_LAUNCH_OK(h, hipGetLastError());
+    DCP_HIP_OK(h, hipMemcpyAsync(hostv, part, sizeof(double) * blocks, hipMemcpyDeviceToHost, h->stream));
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    double acc = 0.0;
+    for (int i = 0; i < blocks; ++i) acc += reinterpret_cast<double*>(hostv)[i];
+    *out = acc;
+    return DCP_OK;
+}
+
 // D_new = l2_strict(rule(D, P, Q)) and max|D - D_new| (host):
 //   alpha < 0 : D * max(P,0) / max(Q,eps)                         (grads.py:93)
 //   alpha >= 0: max(D * ((1-alpha) + alpha * P / max(Q,eps)), 0)  (kasai.py:77-78)
@@ -397,6 +454,22 @@ int dcp_nmf_grads_f64(dcp_handle* h, const double* Y, const double* mask, double
                       int64_t N, int64_t F, int64_t K, int likelihood, int n_x_updates,
                       double* grad_pos, double* grad_neg) {
     return nmf_grads_api<double>(h, Y, mask, X, D, N, F, K, likelihood, n_x_updates, grad_pos, grad_neg);
+}
+int dcp_nmf_grad_x_f32(dcp_handle* h, const float* Y, const float* mask, const float* X, const float* D,
+                       int64_t N, int64_t F, int64_t K, int likelihood, float* grad_pos, float* grad_neg) {
+    return nmf_grad_x_api<float>(h, Y, mask, X, D, N, F, K, likelihood, grad_pos, grad_neg);
+}
+int dcp_nmf_grad_x_f64(dcp_handle* h, const double* Y, const double* mask, const double* X, const double* D,
+                       int64_t N, int64_t F, int64_t K, int likelihood, double* grad_pos, double* grad_neg) {
+    return nmf_grad_x_api<double>(h, Y, mask, X, D, N, F, K, likelihood, grad_pos, grad_neg);
+}
+int dcp_nmf_gauss_logp_f32(dcp_handle* h, const float* Y, const float* mask, const float* X, const float* D,
+                           int64_t N, int64_t F, int64_t K, double scale, double* out) {
+    return nmf_gauss_logp_api<float>(h, Y, mask, X, D, N, F, K, scale, out);
+}
+int dcp_nmf_gauss_logp_f64(dcp_handle* h, const double* Y, const double* mask, const double* X, const double* D,
+                           int64_t N, int64_t F, int64_t K, double scale, double* out) {
+    return nmf_gauss_logp_api<double>(h, Y, mask, X, D, N, F, K, scale, out);
 }
 int dcp_nmf_apply_f32(dcp_handle* h, const float* D, const float* P, const float* Q, double alpha,
                       float* D_new, int64_t K, int64_t F, double* maxdiff) {

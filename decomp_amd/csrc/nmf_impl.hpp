@@ -350,6 +350,62 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
     return DCP_OK;
 }
 
+// ---- the two parts of the x gradient as explicit arrays (the reference's plugin surface) ------
+// Gaussian.grad_x / Poisson.grad_x (grads.py:108-115, 143-150): pos, neg [N, K].
+//   l2        : pos = (Y o M) D^T,  neg = ((x D) o M) D^T   (no mask: neg = x (D D^T), the Gram identity)
+//   kl        : pos = ((Y o M) / (x D + eps)) D^T,  neg = colsum(D) on every row (no mask) or M D^T
+// (for kl without a mask the reference returns the [1, K] row d.T.sum(axis=0, keepdims=True); the caller
+//  slices row 0 of neg).  Ypre = Y o M (or Y).
+template <class T>
+inline int nmf_grad_x(dcp_handle* h, const T* Ypre, const T* mask, const T* X, const T* D,
+                      const NmfShape<T>& s, T* pos, T* neg, NmfStatsWs<T>& w) {
+    hipStream_t st = h->stream;
+    const int N = (int)s.N, F = (int)s.F, K = (int)s.K;
+    const bool gram = (s.lik == DCP_LIK_L2 && !s.masked);
+    const T* pos_A = Ypre;
+    if (gram) {
+        GemmArgs<T> g;
+        g.A = D; g.lda = F; g.B = D; g.ldb = F; g.M = K; g.N = K; g.K = F;
+        plan_splits<FORM_NT>(g, 512, kMaxSplits, 16);
+        DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, g, EpiSlab<T>{w.slabs, K, (long)K * K})));
+        hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * K)), dim3(256), 0, st, w.slabs,
+                           (long)K * K, g.ksplits, (long)K * K, w.G);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        GemmArgs<T> q;
+        q.A = X; q.lda = K; q.B = w.G; q.ldb = K; q.M = N; q.N = K; q.K = K;
+        DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, q, EpiStore<T>{neg, K})));
+    } else {
+        GemmArgs<T> fa;
+        fa.A = X; fa.lda = K; fa.B = D; fa.ldb = F; fa.M = N; fa.N = F; fa.K = K;
+        if (s.lik == DCP_LIK_L2) {
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, fa, EpiMulMask<T>{mask, F, w.f, F})));
+            GemmArgs<T> q;
+            q.A = w.f; q.lda = F; q.B = D; q.ldb = F; q.M = N; q.N = K; q.K = F;
+            DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, q, EpiStore<T>{neg, K})));
+        } else {
+            DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, fa, EpiKlRatio<T>{Ypre, F, nullptr, 0, w.f, F})));
+            pos_A = w.f;
+            if (!s.masked) {
+                hipLaunchKernelGGL((rowsum_kernel<T>), dim3(K), dim3(256), 0, st, D, (long)F, (long)F, w.vecK);
+                DCP_LAUNCH_OK(h, hipGetLastError());
+                // neg[n, k] = colsum(D)[k] for every n: bcast_rows_kernel writes out[r, c] = v[r], so build the
+                // transposed broadcast with the quotient kernel's column mode instead: one pass, den_bcast = 2
+                hipLaunchKernelGGL((bcast_cols_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st,
+                                   (const T*)w.vecK, (long)N, (long)K, neg);
+                DCP_LAUNCH_OK(h, hipGetLastError());
+            } else {
+                GemmArgs<T> q;
+                q.A = mask; q.lda = F; q.B = D; q.ldb = F; q.M = N; q.N = K; q.K = F;
+                DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, q, EpiStore<T>{neg, K})));
+            }
+        }
+    }
+    GemmArgs<T> pg;
+    pg.A = pos_A; pg.lda = F; pg.B = D; pg.ldb = F; pg.M = N; pg.N = K; pg.K = F;
+    DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, pg, EpiStore<T>{pos, K})));
+    return DCP_OK;
+}
+
 // ---- D update from the (all-reduced) statistics ---------------------------------------
 template <class T>
 inline int nmf_update(dcp_handle* h, const T* stats, const T* D, T* D_new, int64_t F64, int64_t K64,

@@ -453,17 +453,11 @@ int dcp_destroy(dcp_handle* h) {
 
 int dcp_set_stream(dcp_handle* h, void* hip_stream) {
     if (!h) return DCP_ERR_INVALID;
-    hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
-    if (next != h->stream && h->arena != nullptr) {
-        // The workspace arena is shared by every call on this handle: work already enqueued on the
-        // old stream may still be using it, so the new stream waits for it (an event, no host sync).
-        DCP_HIP_OK(h, hipSetDevice(h->device));
-        if (h->stream_switch == nullptr)
-            DCP_HIP_OK(h, hipEventCreateWithFlags(&h->stream_switch, hipEventDisableTiming));
-        DCP_HIP_OK(h, hipEventRecord(h->stream_switch, h->stream));
-        DCP_HIP_OK(h, hipStreamWaitEvent(next, h->stream_switch, 0));
-    }
-    h->stream = next;
+    // Only the handle's current stream changes here.  Ordering of the shared workspace arena between
+    // the old and the new stream is established lazily by the next call that actually uses the arena
+    // (ws_reserve -> ws_order_streams); calls that use none (dcp_gather_rows_bytes / dcp_scatter_rows_bytes
+    // on a copy stream) therefore overlap freely with compute enqueued on the other stream.
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return DCP_OK;
 }
 

@@ -34,10 +34,9 @@ def _likelihood_code(likelihood):
             return _hip.LIK_L2
         if likelihood in ('kl', 'poisson'):
             return _hip.LIK_KL
-    elif type(likelihood) in (grads.Gaussian, grads.Poisson):
-        return likelihood._code
     elif isinstance(likelihood, grads.Likelihood):
-        return likelihood
+        code = grads.fused_code(likelihood)
+        return likelihood if code is None else code
     raise NotImplementedError('Likelihood {} is not implemented for nmf'.format(likelihood))
 
 

@@ -53,7 +53,12 @@ enum { DCP_LASSO_POSITIVE = 0x100 };
 /* ---- lifetime ----------------------------------------------------------------- */
 int dcp_create(dcp_handle** out, int device);
 int dcp_destroy(dcp_handle* h);
-/* hipStream_t passed as void*; NULL = the device's default stream */
+/* hipStream_t passed as void*; NULL = the device's default stream.  Cheap (no HIP call): the library's
+ * workspace is ordered between the old and the new stream by the next call that uses workspace (an event
+ * wait on the device, no host synchronisation); the row movers use none and are never ordered against
+ * other streams' work.  LIFETIME: a stream handed to the handle must stay alive until work enqueued on it
+ * through this handle has completed or a later workspace-using call on another stream has been issued
+ * (if its event can no longer be recorded the library falls back to a device synchronisation). */
 int dcp_set_stream(dcp_handle* h, void* hip_stream);
 const char* dcp_last_error_string(dcp_handle* h);
 /* compile-time facts, for the loader's sanity check */
@@ -205,6 +210,20 @@ int dcp_nmf_grads_f32(dcp_handle* h, const float* Y, const float* mask, float* X
 int dcp_nmf_grads_f64(dcp_handle* h, const double* Y, const double* mask, double* X, const double* D,
                       int64_t N, int64_t F, int64_t K, int likelihood, int n_x_updates,
                       double* grad_pos, double* grad_neg);
+/* Gaussian.grad_x / Poisson.grad_x (decomp/nmf_methods/grads.py:108-115, 143-150), the plugin surface a
+ * user subclass reaches through super(): grad_pos, grad_neg [N, K].  Without a mask the l2 negative part
+ * is x (D D^T) (the Gram identity of (x D) D^T) and the kl negative part -- the reference's [1, K] row
+ * d.T.sum(axis=0) -- is repeated on every row.  X is not modified.  Asynchronous. */
+int dcp_nmf_grad_x_f32(dcp_handle* h, const float* Y, const float* mask, const float* X, const float* D,
+                       int64_t N, int64_t F, int64_t K, int likelihood, float* grad_pos, float* grad_neg);
+int dcp_nmf_grad_x_f64(dcp_handle* h, const double* Y, const double* mask, const double* X, const double* D,
+                       int64_t N, int64_t F, int64_t K, int likelihood, double* grad_pos, double* grad_neg);
+/* Gaussian.logp (grads.py:127-135): sum((-0.5 ((y - x d) / scale)^2 - log(scale) - pi / 2) [* mask]) to the
+ * HOST double (accumulated in double precision).  Synchronises. */
+int dcp_nmf_gauss_logp_f32(dcp_handle* h, const float* Y, const float* mask, const float* X, const float* D,
+                           int64_t N, int64_t F, int64_t K, double scale, double* out);
+int dcp_nmf_gauss_logp_f64(dcp_handle* h, const double* Y, const double* mask, const double* X, const double* D,
+                           int64_t N, int64_t F, int64_t K, double scale, double* out);
 int dcp_nmf_apply_f32(dcp_handle* h, const float* D, const float* P, const float* Q, double alpha,
                       float* D_new, int64_t K, int64_t F, double* maxdiff);
 int dcp_nmf_apply_f64(dcp_handle* h, const double* D, const double* P, const double* Q, double alpha,
@@ -241,8 +260,9 @@ int dcp_nmf_residual_f64(dcp_handle* h, const double* Y, const double* mask, con
  * the `_pos` (NNLS) proximal operator (real dtypes only, lasso.py:92).
  * *it_out (host) is the reference's iteration count: the index of the first iteration
  * i % 10 == 0 at which max(|dx| - tol) < 0, else maxiter - 1 (with the reference's
- * choice of returned iterate per method, lasso.py:297,357,415).  The coordinate-descent
- * solver supports K <= 2048.  Synchronises the stream before returning. */
+ * choice of returned iterate per method, lasso.py:297,357,415).  Coordinate descent has no size
+ * limit (K <= 2048: a row's coefficients live in one wave's registers; wider: in that row's memory).
+ * Synchronises the stream before returning. */
 int dcp_lasso_f32(dcp_handle* h, const float* Y, const float* mask, int mask_ndim, const float* A,
                   float* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
                   int method, int positive, int* it_out);
@@ -281,7 +301,7 @@ int dcp_lasso_pcd_c128(dcp_handle* h, const void* Y, const double* mask, int mas
 /* decomp/lasso.py:586-657 `_solve_admm(_mask)` with penalty rho (dcp_lasso_* with
  * DCP_LASSO_ADMM uses rho = 1.0 like solve_fastpath).  (A A^H + rho I)^-1 is formed on the
  * device in double precision (math_utils/linalg.py:9-16); a 2-D mask needs one K x K system
- * per row (N K^2 workspace, K <= 2048). */
+ * per row (N K^2 workspace, as the reference's lasso.py:643; K <= 10240 real / 5120 complex). */
 int dcp_lasso_admm_f32(dcp_handle* h, const float* Y, const float* mask, int mask_ndim, const float* A,
                        float* X, int64_t N, int64_t F, int64_t K, double alpha, double tol, int maxiter,
                        int positive, double rho, int* it_out);

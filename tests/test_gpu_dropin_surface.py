@@ -225,3 +225,102 @@ def test_axpby_zero_coefficient_semantics():
     z[0, 0] = 4.0
     kern.axpby(0.0, z, 0.5, z)                       # aliasing, a = 0: plain scaling, inf stays inf
     assert z[0, 0].item() == 2.0 and torch.isinf(z[1, 1]).item()
+
+
+@pytest.mark.parametrize('lik', ['l2', 'kl'])
+@pytest.mark.parametrize('masked', [False, True])
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_builtin_likelihood_methods_match_reference_parts(lik, masked, dtype):
+    """Gaussian / Poisson .grad_x / .grad_d / .update_x / .update_d called directly, as the reference allows
+    (grads.py:77-93, 108-125, 143-160): values AND shapes (Poisson without a mask returns the broadcastable
+    [1, K] / [K, 1] sums) against the oracle's restatement of those lines."""
+    import decomp_amd as decomp
+    from oracle import nmf as onmf
+    g = decomp.nmf_methods.grads
+    rng = np.random.RandomState(11)
+    y, D0, mask = _problem(rng, N=203, F=36, K=5, dtype=dtype)
+    x = np.abs(rng.randn(203, 5)).astype(dtype)
+    m = mask if masked else None
+    obj = g.Gaussian() if lik == 'l2' else g.Poisson()
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    for mine, ref in ((obj.grad_x(y, x, D0, m), onmf._parts_x(y, x, D0, m, lik)),
+                      (obj.grad_d(y, x, D0, m), onmf._parts_d(y, x, D0, m, lik))):
+        for a, b in zip(mine, ref):
+            assert isinstance(a, np.ndarray) and a.dtype == dtype and a.shape == b.shape, (a.shape, b.shape)
+            assert np.max(np.abs(a - b)) <= tol * max(1.0, np.max(np.abs(b)))
+    xu = obj.update_x(y, x, D0, m)
+    du = obj.update_d(y, x, D0, m)
+    assert np.max(np.abs(xu - onmf.update_x(y, x, D0, m, lik))) <= tol * max(1.0, np.max(xu))
+    assert np.max(np.abs(du - onmf.update_d(y, x, D0, m, lik))) <= tol * max(1.0, np.max(du))
+
+
+def test_gaussian_logp_and_poisson_logp_quirk():
+    """Gaussian.logp (grads.py:127-135, incl. its `pi * 0.5` constant and the scale) with and without a
+    (fractional) mask; Poisson.logp raises AttributeError as the reference's does (grads.py:162-165)."""
+    import torch
+    import decomp_amd as decomp
+    g = decomp.nmf_methods.grads
+    rng = np.random.RandomState(12)
+    y, D0, mask = _problem(rng, N=150, F=33, K=4)
+    x = np.abs(rng.randn(150, 4))
+    frac = mask * rng.uniform(0.2, 1.0, size=mask.shape)
+    for scale in (1.0, 2.5):
+        for m in (None, mask, frac):
+            loss = np.square((y - x.dot(D0)) / scale)
+            want = -0.5 * loss - np.log(scale) - np.pi * 0.5
+            want = np.sum(want) if m is None else np.sum(want * m)
+            got = g.Gaussian(scale=scale).logp(y, x, D0, m)
+            assert abs(got - want) <= 1e-10 * abs(want), (scale, got, want)
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).cuda()
+    got = g.Gaussian().logp(t(y), t(x), t(D0), None)
+    assert got.is_cuda and got.dtype == torch.float32
+    want = np.sum(-0.5 * np.square(y - x.dot(D0)) - np.pi * 0.5)
+    assert abs(float(got) - want) <= 1e-5 * abs(want)
+    with pytest.raises(AttributeError):
+        g.Poisson().logp(y, x, D0, None)
+
+
+def test_subclass_of_builtin_overriding_one_method():
+    """The reference's extension point with inheritance (grads.py:96-160): `class Mine(Gaussian)` that
+    overrides ONE gradient reaches the other through the base class (host loop), and a subclass that only
+    overrides logp keeps the fused kernels -- both give the built-in 'l2' iterates."""
+    import decomp_amd as decomp
+    from oracle import nmf as onmf
+    g = decomp.nmf_methods.grads
+    rng = np.random.RandomState(13)
+    y, D0, mask = _problem(rng)
+
+    class OnlyGradX(g.Gaussian):
+        calls = 0
+
+        def grad_x(self, y, x, d, mask):
+            OnlyGradX.calls += 1
+            f = x @ d
+            if mask is not None:
+                f, y = f * mask, y * mask
+            return y @ d.T, f @ d.T
+
+    class OnlyLogp(g.Gaussian):
+        def logp(self, y, x, d, mask):
+            return 0.0
+
+    assert g.fused_code(OnlyLogp()) == g.Gaussian._code and g.fused_code(OnlyGradX()) is None
+    for m in (None, mask):
+        ito, Do, xo = onmf.solve(y, D0.copy(), tol=1e-4, maxiter=40, mask=m)
+        it, D, x = decomp.nmf.solve(y, D0.copy(), tol=1e-4, maxiter=40, likelihood=OnlyGradX(), mask=m)
+        assert it == ito and np.max(np.abs(D - Do)) < 1e-9 and np.max(np.abs(x - xo)) < 1e-8 * max(1.0, np.max(xo))
+        it2, D2, x2 = decomp.nmf.solve(y, D0.copy(), tol=1e-4, maxiter=40, likelihood=OnlyLogp(), mask=m)
+        itb, Db, xb = decomp.nmf.solve(y, D0.copy(), tol=1e-4, maxiter=40, likelihood='l2', mask=m)
+        assert it2 == itb and np.array_equal(D2, Db) and np.array_equal(x2, xb)
+    assert OnlyGradX.calls > 0
+
+    class KlOnlyGradD(g.Poisson):
+        def grad_d(self, y, x, d, mask):
+            f = x @ d + 1.0e-15
+            if mask is None:
+                return x.T @ (y / f), x.T.sum(axis=1, keepdims=True)
+            return x.T @ ((y * mask) / f), x.T @ mask
+    for m in (None, mask):
+        ito, Do, xo = onmf.solve(y, D0.copy(), tol=0.0, maxiter=12, likelihood='kl', mask=m)
+        it, D, x = decomp.nmf.solve(y, D0.copy(), tol=0.0, maxiter=12, likelihood=KlOnlyGradD(), mask=m)
+        assert it == ito == 12 and np.max(np.abs(D - Do)) < 1e-9

@@ -198,3 +198,54 @@ def test_random_shapes_against_oracle(dt):
         assert x.shape == xo.shape and x.dtype == y.dtype
         e = _err(x, xo)
         assert e < tol, (dt, trial, N, F, K, method, mkind, e)
+
+
+@pytest.mark.parametrize('dt,K', [('float64', 2112), ('float32', 2112), ('complex128', 2112), ('float64', 4160)])
+def test_coordinate_descent_wider_than_2048_atoms(dt, K):
+    """The reference's coordinate descent has no width limit (lasso.py:526-552); beyond the 2048 atoms a
+    wave's registers hold, the sweep keeps a row's x and g in memory (cd_gram_wide_kernel).  Against the
+    oracle's as-written sweep; method 'cd' and 'parallel_cd' (whose p <= 1 fallback is cd: with K > F the
+    Gershgorin bound exceeds K / 2)."""
+    import decomp_amd as decomp
+    from oracle import lasso as olasso
+    rng = np.random.RandomState(K)
+    cplx = dt.startswith('complex')
+    N, F = 9, 48
+
+    def randn(*s):
+        return (rng.randn(*s) + 1j * rng.randn(*s)) if cplx else rng.randn(*s)
+    A = randn(K, F).astype(dt)
+    xt = (randn(N, K) * (rng.uniform(size=(N, K)) < 0.01)).astype(dt)
+    y = (xt @ A + 0.05 * randn(N, F)).astype(dt)
+    single = dt == 'float32'
+    for method in ('cd', 'parallel_cd'):
+        ito, xo = olasso.solve(y.copy(), A.copy(), 0.05, tol=1e-4, method=method, maxiter=12)
+        it, x = decomp.lasso.solve(y.copy(), A.copy(), 0.05, tol=1e-4, method=method, maxiter=12)
+        assert x.dtype == y.dtype and x.shape == (N, K)
+        scale = max(1.0, float(np.max(np.abs(xo))))
+        if single:
+            assert abs(it - ito) <= 10 and np.max(np.abs(x - xo)) < 2e-3 * scale
+        else:
+            assert it == ito and np.max(np.abs(x - xo)) < 1e-8 * scale, (method, it, ito)
+
+
+def test_wide_coordinate_descent_equals_register_form_bitwise(monkeypatch):
+    """cd_gram_wide_kernel does the arithmetic of cd_gram_kernel in the same order: with the register form's
+    limit lowered through DCP_CD_REGISTER_LIMIT (a test knob) a 1500-atom problem takes the wide form and
+    must reproduce the register form's codes bit for bit (real and complex)."""
+    import decomp_amd as decomp
+    rng = np.random.RandomState(3)
+    for dt in ('float32', 'complex64', 'float64'):
+        cplx = dt.startswith('complex')
+        N, F, K = 37, 96, 1500
+
+        def randn(*s):
+            return (rng.randn(*s) + 1j * rng.randn(*s)) if cplx else rng.randn(*s)
+        A = randn(K, F).astype(dt)
+        y = ((randn(N, K) * (rng.uniform(size=(N, K)) < 0.02)) @ A + 0.05 * randn(N, F)).astype(dt)
+        monkeypatch.delenv('DCP_CD_REGISTER_LIMIT', raising=False)
+        it_a, x_a = decomp.lasso.solve(y.copy(), A.copy(), 0.05, tol=1e-5, method='cd', maxiter=21)
+        monkeypatch.setenv('DCP_CD_REGISTER_LIMIT', '1024')
+        it_b, x_b = decomp.lasso.solve(y.copy(), A.copy(), 0.05, tol=1e-5, method='cd', maxiter=21)
+        assert it_a == it_b and np.array_equal(x_a, x_b), dt
+        assert np.count_nonzero(x_a) > 0
