@@ -48,12 +48,6 @@ __device__ __forceinline__ bool gb_wait_ge(unsigned* word, unsigned target, unsi
 }
 
 // epoch: 1 for the first barrier of the launch, 2 for the second, ...  Uniform across the grid.
-// WRITE_THROUGH = true: the caller stored EVERY byte other workgroups will read after this barrier with
-// write-through (sc1) stores (st_sc1_* below), so no L2 write-back (release fence) is needed before the
-// arrival: Guideline 16 recipe R1 -- sc1 payload, every storing wave drained, one lane signals, the consumer
-// acquires once and then loads plainly.  The release fence costs 2-7 us per barrier when tens of KB per
-// workgroup are dirty (microarch table "publish-large").
-template <bool WRITE_THROUGH = false>
 __device__ __forceinline__ void grid_barrier(GridBarrierState* bs, unsigned epoch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every wave: its stores have left
     __syncthreads();
@@ -62,10 +56,8 @@ __device__ __forceinline__ void grid_barrier(GridBarrierState* bs, unsigned epoc
         const unsigned ngroups = nwg < 8u ? nwg : 8u;
         const unsigned g = blockIdx.x & 7u;
         const unsigned members = (nwg - g + 7u) >> 3;
-        if (!WRITE_THROUGH) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned prev = __hip_atomic_fetch_add(&bs->group_count[g].v, 1u, DCP_RLX_AGENT);
         if (prev + 1u == epoch * members) {
             __hip_atomic_fetch_add(&bs->top.v, 1u, DCP_RLX_AGENT);
@@ -80,14 +72,21 @@ __device__ __forceinline__ void grid_barrier(GridBarrierState* bs, unsigned epoc
     __syncthreads();
 }
 
-// End of the kernel, after the last grid_barrier: every workgroup draws a ticket; the ONE workgroup that
-// draws the last ticket -- by then every other workgroup has left its last barrier -- re-zeroes the barrier
-// state for the next launch.  No data is handed over here (no fences) and no workgroup waits.
-__device__ __forceinline__ void grid_barrier_finish(GridBarrierState* bs) {
+// End of the kernel, after the last grid_barrier: every workgroup draws a ticket (its own stores published
+// first); returns true in the ONE workgroup that drew the last ticket -- by then every other workgroup has
+// left its last barrier, so that workgroup (a) may read what the others published before their ticket and
+// (b) re-zeroes the barrier state for the next launch.  No workgroup waits here.
+__device__ __forceinline__ bool grid_barrier_finish(GridBarrierState* bs, int* s_last /* LDS word */) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned prev = __hip_atomic_fetch_add(&bs->ticket.v, 1u, DCP_RLX_AGENT);
         const bool last = (prev + 1u == gridDim.x);
         if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             for (int g = 0; g < 8; ++g) {
                 __hip_atomic_store(&bs->group_count[g].v, 0u, DCP_RLX_AGENT);
                 __hip_atomic_store(&bs->group_gen[g].v, 0u, DCP_RLX_AGENT);
@@ -95,21 +94,10 @@ __device__ __forceinline__ void grid_barrier_finish(GridBarrierState* bs) {
             __hip_atomic_store(&bs->top.v, 0u, DCP_RLX_AGENT);
             __hip_atomic_store(&bs->ticket.v, 0u, DCP_RLX_AGENT);
         }
+        *s_last = last ? 1 : 0;
     }
-}
-
-// Write-through (sc1) stores through a raw buffer descriptor: base = a wave-uniform pointer, byte offset per
-// lane (< 4 GiB).  The bytes go to memory without staying dirty in this XCD's L2.
-typedef unsigned gb_u32x4 __attribute__((ext_vector_type(4)));
-typedef float gb_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t gb_rsrc(void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ void st_sc1_f4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, gb_f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gb_u32x4, v), r, byte_off, 0, 16);
-}
-__device__ __forceinline__ void st_sc1_f1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 16);
+    __syncthreads();
+    return *s_last != 0;
 }
 
 }  // namespace dcp

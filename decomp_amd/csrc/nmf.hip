@@ -86,7 +86,6 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     // the fused launch writes max|dD| (and its status word) straight into the pinned host slots
     T* host_md_dev = host_md;
     int* host_status_dev = host_status;
-    const bool md_via_copy = fused && getenv("DCP_FUSED_MD_DEVICE") != nullptr;   // analysis knob
     if (fused) {
         void* dp = nullptr;
         DCP_HIP_OK(h, hipHostGetDevicePointer(&dp, hostv, 0));
@@ -131,11 +130,7 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
                                      /*keep_slabs=*/true));
                 ProfScope ps(h, DCP_PROF_DUPDATE);
                 DCP_TRY(nmf_fused_update(h, ws.slabs, ws.stat_nslabs, ws.stat_stride, Dc, Dn, ws.G, F, K,
-                                         md_via_copy ? maxdiff_dev + slot : host_md_dev + slot, nullptr,
-                                         md_via_copy ? nullptr : host_status_dev + slot, fw));
-                if (md_via_copy)
-                    DCP_HIP_OK(h, hipMemcpyAsync(host_md + slot, maxdiff_dev + slot, sizeof(T),
-                                                 hipMemcpyDeviceToHost, h->stream));
+                                         host_md_dev + slot, nullptr, host_status_dev + slot, fw));
             }
         }
         if (!fused) {
