@@ -116,15 +116,6 @@ SIGNATURES = {
                                       _c_i64, _c_int, _c_vp]),
     'dcp_nmf_mu_stats_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64,
                                       _c_i64, _c_int, _c_vp]),
-    'dcp_nmf_fused_update_available': (_c_int, [_c_i64, _c_i64, _c_int, _c_int, _c_int]),
-    'dcp_nmf_mu_stats_g_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64,
-                                        _c_i64, _c_int, _c_vp]),
-    'dcp_nmf_mu_stats_g_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64,
-                                        _c_i64, _c_int, _c_vp]),
-    'dcp_nmf_mu_update_g_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_int,
-                                         _c_int, _c_vp, _c_vp]),
-    'dcp_nmf_mu_update_g_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_int,
-                                         _c_int, _c_vp, _c_vp]),
     'dcp_nmf_mask_bits_words': (_c_i64, [_c_i64, _c_i64]),
     'dcp_nmf_mask_prepare_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _P(_c_int)]),
     'dcp_nmf_mask_prepare_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_vp, _P(_c_int)]),

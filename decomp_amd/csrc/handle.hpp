@@ -35,8 +35,6 @@ struct dcp_handle {
     void* host_pinned = nullptr;
     size_t host_pinned_bytes = 0;
     std::string err;
-    // state of the grid barrier of the fused D-side launch (grid_barrier.hpp): its own small device buffer
-    void* grid_barrier = nullptr;
     // parallel_cd inside the dictionary step: the caller-supplied shuffle table (dcp_dict_set_pcd_order)
     const int* pcd_order = nullptr;
     int64_t pcd_rows = 0, pcd_K = 0;

@@ -44,9 +44,6 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
         plan.add<uint32_t>(mask_bits_words(N, F));
         plan.add<int>(4);
     }
-    // float32, l2, no mask: the whole replicated D side of an iteration is ONE launch (nmf_fused_update.hpp)
-    const bool fused = gram && std::is_same<T, float>::value && fused_update_usable(F, K);
-    if (fused) fused_update_ws_plan(plan, F, K);
     if (want_resid) {
         if (gram) plan.add<T>((size_t)N * F);
         plan.add<double>(resid_blocks);
@@ -76,23 +73,10 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     }
     if (!stats || !D2 || !X2 || !maxdiff_dev || (want_resid && (!resid_tmp || !resid_part)))
         return fail(h, DCP_ERR_INTERNAL, "nmf workspace plan mismatch");
-    FusedUpdWs fw;
-    if (fused) DCP_TRY(fused_update_ws_carve(h, fw, F, K));
     void* hostv = nullptr;
     DCP_TRY(host_scratch(h, sizeof(double) * (resid_blocks + 4), &hostv));
     T* host_md = reinterpret_cast<T*>(hostv);             // [2]
-    int* host_status = reinterpret_cast<int*>(reinterpret_cast<double*>(hostv) + 2);   // [2] (fused launch)
-    double* host_part = reinterpret_cast<double*>(hostv) + 4;
-    // the fused launch writes max|dD| (and its status word) straight into the pinned host slots
-    T* host_md_dev = host_md;
-    int* host_status_dev = host_status;
-    if (fused) {
-        void* dp = nullptr;
-        DCP_HIP_OK(h, hipHostGetDevicePointer(&dp, hostv, 0));
-        host_md_dev = reinterpret_cast<T*>(dp);
-        host_status_dev = reinterpret_cast<int*>(reinterpret_cast<double*>(dp) + 2);
-        host_status[0] = host_status[1] = 0;
-    }
+    double* host_part = reinterpret_cast<double*>(hostv) + 2;
     hipEvent_t ev[2] = {nullptr, nullptr};
     DCP_HIP_OK(h, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     DCP_HIP_OK(h, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
@@ -122,24 +106,11 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     bool converged = false;
     for (int it = 1; it < maxiter; ++it) {  // batch_mu.py:16
         const int slot = it & 1;
-        if constexpr (std::is_same<T, float>::value) {
-            if (fused) {
-                // statistics stay as split-K partials; the fused launch sums them, updates D, forms the next
-                // iteration's Gram matrix in ws.G and writes max|dD| to the host slot
-                DCP_TRY(nmf_stats<T>(h, Ypre, mask, Xc, Xn, Dc, s, stats, ws, 3, /*g_ready=*/it > 1,
-                                     /*keep_slabs=*/true));
-                ProfScope ps(h, DCP_PROF_DUPDATE);
-                DCP_TRY(nmf_fused_update(h, ws.slabs, ws.stat_nslabs, ws.stat_stride, Dc, Dn, ws.G, F, K,
-                                         host_md_dev + slot, nullptr, host_status_dev + slot, fw));
-            }
-        }
-        if (!fused) {
-            DCP_TRY(nmf_stats<T>(h, Ypre, mask, Xc, Xn, Dc, s, stats, ws));
-            DCP_TRY(nmf_update<T>(h, stats, Dc, Dn, F, K, lik, masked, maxdiff_dev + slot, wu,
-                                  maxdiff_dev + (slot ^ 1)));
-            DCP_HIP_OK(h, hipMemcpyAsync(host_md + slot, maxdiff_dev + slot, sizeof(T),
-                                         hipMemcpyDeviceToHost, h->stream));
-        }
+        DCP_TRY(nmf_stats<T>(h, Ypre, mask, Xc, Xn, Dc, s, stats, ws));
+        DCP_TRY(nmf_update<T>(h, stats, Dc, Dn, F, K, lik, masked, maxdiff_dev + slot, wu,
+                              maxdiff_dev + (slot ^ 1)));
+        DCP_HIP_OK(h, hipMemcpyAsync(host_md + slot, maxdiff_dev + slot, sizeof(T),
+                                     hipMemcpyDeviceToHost, h->stream));
         DCP_HIP_OK(h, hipEventRecord(ev[slot], h->stream));
         if (want_resid) {   // parity/debug mode: synchronous
             DCP_TRY(nmf_residual<T>(h, Y, mask, Xn, Dn, N, F, K, resid_tmp, resid_part,
@@ -154,7 +125,6 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
         if (it > 1) {   // stop test of the PREVIOUS iteration
             DCP_HIP_OK(h, hipEventSynchronize(ev[slot ^ 1]));
             md_last = host_md[slot ^ 1];
-            if (fused && host_status[slot ^ 1] != 0) return fused_update_expired(h);
             if (md_last < tol) {   // a NaN compares false, as in NumPy
                 result_it = it - 1;
                 converged = true;
@@ -168,7 +138,6 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
         const int slot = (maxiter - 1) & 1;
         DCP_HIP_OK(h, hipEventSynchronize(ev[slot]));
         md_last = host_md[slot];
-        if (fused && host_status[slot] != 0) return fused_update_expired(h);
         if (md_last < tol) result_it = maxiter - 1;
     }
     DCP_HIP_OK(h, hipStreamSynchronize(h->stream));   // drain (incl. a discarded iteration)
@@ -186,7 +155,7 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
 
 template <class T>
 int nmf_mu_stats_api(dcp_handle* h, const T* Y, const T* mask, const T* X, T* X_out, const T* D,
-                     int64_t N, int64_t F, int64_t K, int lik, T* stats, const T* G_in = nullptr) {
+                     int64_t N, int64_t F, int64_t K, int lik, T* stats) {
     DCP_TRY(check_nmf_args(h, Y, X, D, N, F, K, lik));
     if (!stats || !X_out) return fail(h, DCP_ERR_INVALID, "stats / X_out is null");
     DCP_HIP_OK(h, hipSetDevice(h->device));
@@ -205,10 +174,7 @@ int nmf_mu_stats_api(dcp_handle* h, const T* Y, const T* mask, const T* X, T* X_
         DCP_HIP_OK(h, hipGetLastError());
         Ypre = ws.Ym;
     }
-    // the caller's D D^T (left by dcp_nmf_mu_update_g_*) replaces the Gram product of this call
-    const bool g_ready = G_in != nullptr && lik == DCP_LIK_L2 && !masked;
-    if (g_ready) ws.G = const_cast<T*>(G_in);
-    return nmf_stats<T>(h, Ypre, mask, X, X_out, D, s, stats, ws, 3, g_ready);
+    return nmf_stats<T>(h, Ypre, mask, X, X_out, D, s, stats, ws);
 }
 
 // dcp_nmf_mu_stats_* with the loop-invariant mask work done once by dcp_nmf_mask_prepare_*.
@@ -247,48 +213,20 @@ int nmf_mask_prepare_api(dcp_handle* h, const T* Y, const T* mask, int64_t N, in
 
 template <class T>
 int nmf_mu_update_api(dcp_handle* h, const T* stats, const T* D, T* D_new, int64_t F, int64_t K,
-                      int lik, int masked, T* maxdiff_dev, T* maxdiff_next, T* G_out = nullptr) {
+                      int lik, int masked, T* maxdiff_dev, T* maxdiff_next) {
     if (!h) return DCP_ERR_INVALID;
     if (!stats || !D || !D_new || !maxdiff_dev) return fail(h, DCP_ERR_INVALID, "null pointer");
     if (F <= 0 || K <= 0) return fail(h, DCP_ERR_INVALID, "sizes must be positive");
     DCP_HIP_OK(h, hipSetDevice(h->device));
-    const bool gram = (lik == DCP_LIK_L2 && masked == 0);
-    if (G_out != nullptr && !gram) return fail(h, DCP_ERR_INVALID, "G_out: l2 without mask only");
     // NOTE: shares the arena with dcp_nmf_mu_stats_*: the stats call's temporaries are dead
     // by now (same stream), `stats` itself is caller memory.
-    if constexpr (std::is_same<T, float>::value) {
-        if (G_out != nullptr && fused_update_usable(F, K)) {
-            // ONE launch: quotient, l2_strict, max|dD| and the Gram matrix of the new dictionary
-            WsPlan plan;
-            fused_update_ws_plan(plan, F, K);
-            DCP_TRY(ws_reserve(h, plan.total));
-            ws_reset(h);
-            FusedUpdWs fw;
-            DCP_TRY(fused_update_ws_carve(h, fw, F, K));
-            ProfScope ps(h, DCP_PROF_DUPDATE);
-            return nmf_fused_update(h, stats, 0, 0, D, D_new, G_out, F, K, maxdiff_dev, maxdiff_next, nullptr, fw);
-        }
-    }
     WsPlan plan;
     nmf_plan_update<T>(plan, F, K);
-    if (G_out != nullptr) plan.add<T>((size_t)kMaxSplits * K * K);
     DCP_TRY(ws_reserve(h, plan.total));
     ws_reset(h);
     NmfUpdateWs<T> wu;
     DCP_TRY(nmf_carve_update(h, wu, F, K));
-    DCP_TRY(nmf_update<T>(h, stats, D, D_new, F, K, lik, masked != 0, maxdiff_dev, wu, maxdiff_next));
-    if (G_out != nullptr) {   // G_out = D_new D_new^T through the split-K product of the stats call
-        T* slabs = ws_alloc<T>(h, (size_t)kMaxSplits * K * K);
-        if (!slabs) return fail(h, DCP_ERR_INTERNAL, "nmf workspace plan mismatch");
-        GemmArgs<T> g;
-        g.A = D_new; g.lda = F; g.B = D_new; g.ldb = F; g.M = (int)K; g.N = (int)K; g.K = (int)F;
-        plan_splits<FORM_NT>(g, 512, kMaxSplits, 16);
-        DCP_LAUNCH_OK(h, (gemm<FORM_NT>(h->stream, g, EpiSlab<T>{slabs, (long)K, (long)K * K})));
-        hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * K)), dim3(256), 0, h->stream,
-                           (const T*)slabs, (long)K * K, g.ksplits, (long)K * K, G_out);
-        DCP_LAUNCH_OK(h, hipGetLastError());
-    }
-    return DCP_OK;
+    return nmf_update<T>(h, stats, D, D_new, F, K, lik, masked != 0, maxdiff_dev, wu, maxdiff_next);
 }
 
 template <class T>
@@ -573,31 +511,6 @@ int dcp_nmf_mu_stats_f64(dcp_handle* h, const double* Y, const double* mask, con
                          double* X_out, const double* D, int64_t N, int64_t F, int64_t K,
                          int likelihood, double* stats) {
     return nmf_mu_stats_api<double>(h, Y, mask, X, X_out, D, N, F, K, likelihood, stats);
-}
-int dcp_nmf_fused_update_available(int64_t F, int64_t K, int likelihood, int masked, int is_f32) {
-    return (is_f32 != 0 && likelihood == DCP_LIK_L2 && masked == 0 && fused_update_usable(F, K)) ? 1 : 0;
-}
-int dcp_nmf_mu_stats_g_f32(dcp_handle* h, const float* Y, const float* mask, const float* X, float* X_out,
-                           const float* D, const float* G, int64_t N, int64_t F, int64_t K, int likelihood,
-                           float* stats) {
-    return nmf_mu_stats_api<float>(h, Y, mask, X, X_out, D, N, F, K, likelihood, stats, G);
-}
-int dcp_nmf_mu_stats_g_f64(dcp_handle* h, const double* Y, const double* mask, const double* X, double* X_out,
-                           const double* D, const double* G, int64_t N, int64_t F, int64_t K, int likelihood,
-                           double* stats) {
-    return nmf_mu_stats_api<double>(h, Y, mask, X, X_out, D, N, F, K, likelihood, stats, G);
-}
-int dcp_nmf_mu_update_g_f32(dcp_handle* h, const float* stats, const float* D, float* D_new, float* G_out,
-                            int64_t F, int64_t K, int likelihood, int masked, float* maxdiff_dev,
-                            float* maxdiff_next) {
-    return nmf_mu_update_api<float>(h, stats, D, D_new, F, K, likelihood, masked, maxdiff_dev, maxdiff_next,
-                                    G_out);
-}
-int dcp_nmf_mu_update_g_f64(dcp_handle* h, const double* stats, const double* D, double* D_new, double* G_out,
-                            int64_t F, int64_t K, int likelihood, int masked, double* maxdiff_dev,
-                            double* maxdiff_next) {
-    return nmf_mu_update_api<double>(h, stats, D, D_new, F, K, likelihood, masked, maxdiff_dev, maxdiff_next,
-                                     G_out);
 }
 int dcp_nmf_mask_prepare_f32(dcp_handle* h, const float* Y, const float* mask, int64_t N, int64_t F,
                              float* Ym, uint32_t* bits, int* binary) {

@@ -19,7 +19,6 @@
 #include "gemm.hpp"
 #include "handle.hpp"
 #include "kernels_small.hpp"
-#include "nmf_fused_update.hpp"
 
 namespace dcp {
 
@@ -53,9 +52,6 @@ struct NmfStatsWs {
     // float + 0/1 mask: its row-bit image (mask_rowbits_kernel); the forward product then multiplies
     // by bits fetched ahead of its main loop instead of loading the float mask in its epilogue
     const uint32_t* mbits = nullptr;
-    // set by nmf_stats when it leaves the statistics as split-K partials in `slabs` (keep_slabs)
-    int stat_nslabs = 0;
-    long stat_stride = 0;
 };
 
 // Split-K plan of the x-update GEMM (Y D^T, [N,F]x[K,F]): only when the row tiles alone
@@ -175,13 +171,9 @@ inline int column_sums(dcp_handle* h, const T* a, long ld, long rows, long cols,
 // Ypre: Y already multiplied by the mask (or Y itself when there is no mask).
 template <class T>
 inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, T* Xout, const T* D,
-                     const NmfShape<T>& s, T* stats, NmfStatsWs<T>& w, int phases = 3, bool g_ready = false,
-                     bool keep_slabs = false) {
+                     const NmfShape<T>& s, T* stats, NmfStatsWs<T>& w, int phases = 3) {
     // phases: bit 0 = the x update (Xin -> Xout), bit 1 = the D-side sums (with Xout, or with
     // Xin when the x update is skipped)
-    // g_ready: w.G already holds D D^T (left there by the fused D-side launch of the previous iteration)
-    // keep_slabs (l2 without mask only): the statistics stay as ordered split-K partials in w.slabs
-    //   (w.stat_nslabs, w.stat_stride) for nmf_fused_update, which sums them itself; `stats` is not written
     hipStream_t st = h->stream;
     const int N = (int)s.N, F = (int)s.F, K = (int)s.K;
     const bool gram = (s.lik == DCP_LIK_L2 && !s.masked);
@@ -219,7 +211,7 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
     const bool split_gram = gram && std::is_same<T, float>::value && Xout != Xin &&
                             nmf_xupdate_splits<T>(s.N, s.F, s.K, pg_probe) > 1;
     if (gram) {
-        if (!g_ready) {   // G = D D^T  (split over F, partial slabs summed in order)
+        {   // G = D D^T  (split over F, partial slabs summed in order)
             ProfScope ps(h, DCP_PROF_GRAM);
             GemmArgs<T> g;
             g.A = D; g.lda = F; g.B = D; g.ldb = F; g.M = K; g.N = K; g.K = F;
@@ -339,9 +331,6 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
         ProfScope ps(h, DCP_PROF_STATS);
         DCP_LAUNCH_OK(h, (gemm<FORM_TN>(st, sa, EpiSlab<T>{w.slabs, Wg, (long)K * Wg})));
     }
-    w.stat_nslabs = sa.ksplits;
-    w.stat_stride = (long)K * Wg;
-    if (keep_slabs && gram) return DCP_OK;
     ProfScope ps(h, DCP_PROF_STATS_SUM);
     if (Wg == W) {
         hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * W)), dim3(256), 0, st,

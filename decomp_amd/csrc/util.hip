@@ -435,7 +435,6 @@ int dcp_destroy(dcp_handle* h) {
         (void)hipFree(h->arena);
     }
     if (h->host_pinned) (void)hipHostFree(h->host_pinned);
-    if (h->grid_barrier) (void)hipFree(h->grid_barrier);
     for (auto& r : h->prof_recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);

@@ -38,15 +38,6 @@ class HipStepBackend(object):
         self._host = torch.zeros((2,), dtype=D.dtype).pin_memory()
         self._events = [None, None]
         self._ym = self._bits = None
-        # l2 without mask: the Gram matrix D D^T travels from the update of one iteration to the statistics
-        # of the next (dcp_nmf_mu_update_g_* / dcp_nmf_mu_stats_g_*) instead of being recomputed; float32 with
-        # K, F multiples of 4 runs the whole update as ONE launch that also writes max|dD| straight into the
-        # pinned host slot
-        self._gram = (mask is None and lik == _hip.LIK_L2)
-        self._G = torch.empty((self.K, self.K), dtype=D.dtype, device=D.device) if self._gram else None
-        self._G_of = None              # data_ptr of the D that self._G belongs to
-        self._md_on_host = bool(self._gram and lib.dcp_nmf_fused_update_available(
-            self.F, self.K, lik, 0, 1 if self.sfx == 'f32' else 0))
         if mask is not None:
             # loop-invariant mask work, once per run: y o mask and (float32, 0/1 mask) its row bits
             h = _arrays.lib_handle(D)[1]
@@ -67,11 +58,10 @@ class HipStepBackend(object):
                              _arrays.ptr(self.x), _arrays.ptr(self._x_other), _arrays.ptr(D), self.N,
                              self.F, self.K, self.lik, _arrays.ptr(self.stats)), 'dcp_nmf_mu_stats_prepared')
         else:
-            fn = getattr(lib, 'dcp_nmf_mu_stats_g_' + self.sfx)
-            G = self._G if (self._gram and self._G_of == D.data_ptr()) else None
+            fn = getattr(lib, 'dcp_nmf_mu_stats_' + self.sfx)
             _hip.check(h, fn(h, _arrays.ptr(self.y), None, _arrays.ptr(self.x),
-                             _arrays.ptr(self._x_other), _arrays.ptr(D), _arrays.ptr(G), self.N, self.F,
-                             self.K, self.lik, _arrays.ptr(self.stats)), 'dcp_nmf_mu_stats_g')
+                             _arrays.ptr(self._x_other), _arrays.ptr(D), self.N, self.F, self.K,
+                             self.lik, _arrays.ptr(self.stats)), 'dcp_nmf_mu_stats')
         self.x, self._x_other = self._x_other, self.x
         return self.stats
 
@@ -82,22 +72,13 @@ class HipStepBackend(object):
     def update(self, stats, D, D_new, slot):
         """Enqueue the D update; its max|dD| lands asynchronously in host slot ``slot``."""
         lib, h = _arrays.lib_handle(D)
+        fn = getattr(lib, 'dcp_nmf_mu_update_' + self.sfx)
         md = self.maxdiff[slot:slot + 1]            # zero on entry (ping-pong, see the C ABI)
         nxt = self.maxdiff[(slot ^ 1):(slot ^ 1) + 1]
-        if self._gram:
-            fn = getattr(lib, 'dcp_nmf_mu_update_g_' + self.sfx)
-            target = self._host[slot:slot + 1] if self._md_on_host else md
-            _hip.check(h, fn(h, _arrays.ptr(stats), _arrays.ptr(D), _arrays.ptr(D_new), _arrays.ptr(self._G),
-                             self.F, self.K, self.lik, 0, _arrays.ptr(target), _arrays.ptr(nxt)),
-                       'dcp_nmf_mu_update_g')
-            self._G_of = D_new.data_ptr()
-        else:
-            fn = getattr(lib, 'dcp_nmf_mu_update_' + self.sfx)
-            _hip.check(h, fn(h, _arrays.ptr(stats), _arrays.ptr(D), _arrays.ptr(D_new), self.F,
-                             self.K, self.lik, 0 if self.mask is None else 1, _arrays.ptr(md),
-                             _arrays.ptr(nxt)), 'dcp_nmf_mu_update')
-        if not self._md_on_host:
-            self._host[slot:slot + 1].copy_(md, non_blocking=True)
+        _hip.check(h, fn(h, _arrays.ptr(stats), _arrays.ptr(D), _arrays.ptr(D_new), self.F,
+                         self.K, self.lik, 0 if self.mask is None else 1, _arrays.ptr(md),
+                         _arrays.ptr(nxt)), 'dcp_nmf_mu_update')
+        self._host[slot:slot + 1].copy_(md, non_blocking=True)
         ev = self.torch.cuda.Event()
         ev.record()
         self._events[slot] = ev

@@ -167,31 +167,6 @@ int dcp_nmf_mu_stats_f32(dcp_handle* h, const float* Y, const float* mask, const
 int dcp_nmf_mu_stats_f64(dcp_handle* h, const double* Y, const double* mask, const double* X,
                          double* X_out, const double* D, int64_t N, int64_t F, int64_t K,
                          int likelihood, double* stats);
-/* The same pair with the Gram matrix G = D D^T [K, K] (l2 without mask) handed from one iteration to the
- * next instead of being recomputed by the stats call:
- *   dcp_nmf_mu_update_g_* : as dcp_nmf_mu_update_*, and G_out (nullable) <- D_new D_new^T.  float32 with
- *                           K, F multiples of 4: the whole update -- quotient, l2_strict, max|D - D_new|, Gram
- *                           matrix -- is ONE launch with grid barriers (csrc/nmf_fused_update.hpp) instead of
- *                           five latency-bound ones; other cases compute G_out with the split-K product.
- *   dcp_nmf_mu_stats_g_*  : as dcp_nmf_mu_stats_*, using G (nullable; ignored unless l2 without mask) as
- *                           D D^T.  G must belong to the D that is passed.
- *   dcp_nmf_fused_update_available: 1 when dcp_nmf_mu_update_g_* with a non-NULL G_out runs as that one
- *                           launch (is_f32 != 0, l2, no mask, K and F multiples of 4).  maxdiff_dev may then be
- *                           PINNED HOST memory (the launch writes it with one plain store), which saves the
- *                           caller a device-to-host copy per iteration. */
-int dcp_nmf_fused_update_available(int64_t F, int64_t K, int likelihood, int masked, int is_f32);
-int dcp_nmf_mu_stats_g_f32(dcp_handle* h, const float* Y, const float* mask, const float* X, float* X_out,
-                           const float* D, const float* G, int64_t N, int64_t F, int64_t K, int likelihood,
-                           float* stats);
-int dcp_nmf_mu_stats_g_f64(dcp_handle* h, const double* Y, const double* mask, const double* X, double* X_out,
-                           const double* D, const double* G, int64_t N, int64_t F, int64_t K, int likelihood,
-                           double* stats);
-int dcp_nmf_mu_update_g_f32(dcp_handle* h, const float* stats, const float* D, float* D_new, float* G_out,
-                            int64_t F, int64_t K, int likelihood, int masked, float* maxdiff_dev,
-                            float* maxdiff_next);
-int dcp_nmf_mu_update_g_f64(dcp_handle* h, const double* stats, const double* D, double* D_new, double* G_out,
-                            int64_t F, int64_t K, int likelihood, int masked, double* maxdiff_dev,
-                            double* maxdiff_next);
 /* Loop-invariant mask work of a masked run, done ONCE instead of in every dcp_nmf_mu_stats_* call
  * (grads.py:114,124 recompute y * mask per gradient): Ym[N,F] = Y o mask, and -- float32 only, `bits`
  * non-NULL -- the row-bit image of the mask (dcp_nmf_mask_bits_words(N, F) uint32 words: word

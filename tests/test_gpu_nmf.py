@@ -318,115 +318,3 @@ def test_mask_row_bits_identical_to_float_mask_and_fallback(shape):
     it, Dg, xg = decomp_amd.nmf.solve(y, D0.copy(), tol=0.0, maxiter=4, mask=frac)
     ito, Do, xo_ = onmf.solve(y, D0.copy(), tol=0.0, maxiter=4, mask=frac)
     assert np.max(np.abs(Dg - Do)) < 2e-5 and np.max(np.abs(xg - xo_)) < 2e-4 * np.max(np.abs(xo_))
-
-
-# ---- the fused D-side launch (csrc/nmf_fused_update.hpp, grid barriers) ---------------------------------
-def _mu_problem(N, F, K, seed):
-    rng = np.random.RandomState(seed)
-    xt = np.maximum(rng.randn(N, K), 0)
-    Dt = np.maximum(rng.randn(K, F), 0)
-    y = (xt @ Dt + 0.1 * np.abs(rng.randn(N, F))).astype(np.float32)
-    D0 = np.maximum(Dt + 0.3 * rng.randn(K, F), 0.1).astype(np.float32)
-    return y, D0
-
-
-@pytest.mark.parametrize('shape', [(300, 96, 12), (2048, 512, 32), (4096, 1024, 64), (1024, 4096, 256),
-                                   (700, 260, 100), (513, 68, 4), (1024, 2048, 512), (512, 8192, 320),
-                                   (256, 128, 8), (640, 64, 68)])
-def test_fused_update_matches_separate_launches_and_oracle(shape, monkeypatch):
-    """float32 l2 without mask, K and F multiples of 4: the D side of an iteration is ONE launch with grid
-    barriers.  Same iterates as the five separate launches it replaces (DCP_NO_FUSED_UPDATE, a test knob;
-    only summation orders differ), bitwise reproducible, and -- small shapes -- the oracle's iterates.
-    Shapes cover one tile, ragged tiles, exactly one tile per CU and several tiles per workgroup."""
-    import decomp_amd
-    from oracle import nmf as onmf
-    N, F, K = shape
-    y, D0 = _mu_problem(N, F, K, seed=K + F)
-    monkeypatch.delenv('DCP_NO_FUSED_UPDATE', raising=False)
-    a = decomp_amd.nmf.solve(y, D0.copy(), tol=0.0, maxiter=8)
-    b = decomp_amd.nmf.solve(y, D0.copy(), tol=0.0, maxiter=8)
-    assert a[0] == b[0] == 8 and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    monkeypatch.setenv('DCP_NO_FUSED_UPDATE', '1')
-    c = decomp_amd.nmf.solve(y, D0.copy(), tol=0.0, maxiter=8)
-    assert c[0] == 8
-    assert np.all(np.isfinite(a[1])) and abs(np.sum(a[1] * a[1], axis=1) - 1).max() < 1e-5
-    assert _rel(a[1], c[1]) < 2e-5, _rel(a[1], c[1])
-    assert _rel(a[2], c[2]) < 2e-4, _rel(a[2], c[2])
-    if N * F * K <= 1024 * 4096 * 256:
-        o = onmf.solve(y.astype(np.float64), D0.astype(np.float64), tol=0.0, maxiter=8)
-        assert _rel(a[1], o[1]) < 5e-5 and _rel(a[2], o[2]) < 5e-4
-
-
-def test_fused_update_stop_test_and_it(monkeypatch):
-    """The stop rule through the fused launch's host slot: same `it` as the separate launches and the
-    oracle when tol is met (batch_mu.py:22-23), on convergence and on exhaustion."""
-    import decomp_amd
-    from oracle import nmf as onmf
-    y, D0 = _mu_problem(512, 128, 8, seed=3)
-    for tol, maxiter in ((3e-3, 200), (1e-9, 12)):
-        monkeypatch.delenv('DCP_NO_FUSED_UPDATE', raising=False)
-        a = decomp_amd.nmf.solve(y, D0.copy(), tol=tol, maxiter=maxiter)
-        monkeypatch.setenv('DCP_NO_FUSED_UPDATE', '1')
-        c = decomp_amd.nmf.solve(y, D0.copy(), tol=tol, maxiter=maxiter)
-        o = onmf.solve(y.astype(np.float64), D0.astype(np.float64), tol=tol, maxiter=maxiter)
-        assert a[0] == c[0] and abs(a[0] - o[0]) <= 1, (a[0], c[0], o[0])
-        assert _rel(a[1], c[1]) < 5e-5
-
-
-@pytest.mark.parametrize('shape', [(1024, 512, 32), (2048, 4096, 256), (300, 100, 12)])
-@pytest.mark.parametrize('dt', ['float32', 'float64'])
-def test_step_api_with_gram_handover(shape, dt):
-    """dcp_nmf_mu_stats_g_* / dcp_nmf_mu_update_g_* (the Gram matrix travels from the update to the next
-    statistics call; float32: one fused launch writing max|dD| into PINNED HOST memory) against the plain
-    dcp_nmf_mu_stats_* / dcp_nmf_mu_update_* pair, three iterations."""
-    import torch
-    from decomp_amd import _arrays, _hip
-    N, F, K = shape
-    y, D0 = _mu_problem(N, F, K, seed=7)
-    tdt = torch.float32 if dt == 'float32' else torch.float64
-    Y = torch.from_numpy(y).cuda().to(tdt)
-    sfx = 'f32' if dt == 'float32' else 'f64'
-
-    def run(gram):
-        D = torch.from_numpy(D0).cuda().to(tdt)
-        _arrays.l2_normalize_(D, strict=True)
-        Dn = torch.empty_like(D)
-        x, xn = torch.ones((N, K), dtype=tdt, device='cuda'), torch.empty((N, K), dtype=tdt, device='cuda')
-        stats = torch.empty((K, F + K), dtype=tdt, device='cuda')
-        G = torch.empty((K, K), dtype=tdt, device='cuda')
-        md = torch.zeros((2,), dtype=tdt, device='cuda')
-        host = torch.zeros((2,), dtype=tdt).pin_memory()
-        lib, h = _arrays.lib_handle(D)
-        on_host = bool(gram and lib.dcp_nmf_fused_update_available(F, K, _hip.LIK_L2, 0, 1 if sfx == 'f32' else 0))
-        mds = []
-        for it in range(3):
-            slot = it & 1
-            if gram:
-                _hip.check(h, getattr(lib, 'dcp_nmf_mu_stats_g_' + sfx)(
-                    h, _arrays.ptr(Y), None, _arrays.ptr(x), _arrays.ptr(xn), _arrays.ptr(D),
-                    _arrays.ptr(G) if it > 0 else None, N, F, K, _hip.LIK_L2, _arrays.ptr(stats)), 'stats_g')
-                tgt = host[slot:slot + 1] if on_host else md[slot:slot + 1]
-                _hip.check(h, getattr(lib, 'dcp_nmf_mu_update_g_' + sfx)(
-                    h, _arrays.ptr(stats), _arrays.ptr(D), _arrays.ptr(Dn), _arrays.ptr(G), F, K, _hip.LIK_L2, 0,
-                    _arrays.ptr(tgt), _arrays.ptr(md[(slot ^ 1):(slot ^ 1) + 1])), 'update_g')
-                torch.cuda.synchronize()
-                mds.append(float(host[slot]) if on_host else float(md[slot]))
-                Gref = (Dn.double() @ Dn.double().T)
-                assert float((G.double() - Gref).abs().max()) < (1e-5 if sfx == 'f32' else 1e-12)
-            else:
-                _hip.check(h, getattr(lib, 'dcp_nmf_mu_stats_' + sfx)(
-                    h, _arrays.ptr(Y), None, _arrays.ptr(x), _arrays.ptr(xn), _arrays.ptr(D), N, F, K,
-                    _hip.LIK_L2, _arrays.ptr(stats)), 'stats')
-                _hip.check(h, getattr(lib, 'dcp_nmf_mu_update_' + sfx)(
-                    h, _arrays.ptr(stats), _arrays.ptr(D), _arrays.ptr(Dn), F, K, _hip.LIK_L2, 0,
-                    _arrays.ptr(md[slot:slot + 1]), _arrays.ptr(md[(slot ^ 1):(slot ^ 1) + 1])), 'update')
-                torch.cuda.synchronize()
-                mds.append(float(md[slot]))
-            x, xn = xn, x
-            D, Dn = Dn, D
-        return D.cpu().numpy(), x.cpu().numpy(), mds
-    Dg, xg, mg = run(True)
-    Dp, xp, mp = run(False)
-    tol = 3e-5 if dt == 'float32' else 1e-11
-    assert _rel(Dg, Dp) < tol and _rel(xg, xp) < 10 * tol
-    assert np.allclose(mg, mp, rtol=1e-3 if dt == 'float32' else 1e-9, atol=1e-7)
