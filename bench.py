@@ -496,6 +496,44 @@ def main():
     breakdown = read_profile()
     prof_stats = breakdown.get('stats')
 
+    # Multi-GPU (or --force-sharded): where one step's time goes on THIS rank -- local statistics (x update +
+    # x^T [Y | x]), the exchange (ONE all-reduce of [K, F+K]; its time includes waiting for the slowest rank)
+    # and the replicated D update -- from torch events over a few untimed steps; max over ranks reported.
+    phase_ms = None
+    if world > 1 or args.force_sharded:
+        be = sharded.HipStepBackend(Y, None, state['x'], D, _hip.LIK_L2)
+        Dn2 = torch.empty_like(D)
+        Dc2 = D
+        acc = [0.0, 0.0, 0.0]
+        n_ph = 8
+        for it in range(n_ph + 2):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+            st_ = be.local_stats(Dc2)
+            ev[1].record()
+            if world > 1:
+                dist.all_reduce(st_, op=dist.ReduceOp.SUM)
+            ev[2].record()
+            be.update(st_, Dc2, Dn2, it & 1)
+            ev[3].record()
+            torch.cuda.synchronize()
+            if it >= 2:
+                for j in range(3):
+                    acc[j] += ev[j].elapsed_time(ev[j + 1])
+            Dc2, Dn2 = Dn2, Dc2
+        state['x'] = be.x
+        t3 = torch.tensor([a_ / n_ph for a_ in acc], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        K_, W_ = N_ATOMS, N_FEAT + N_ATOMS
+        phase_ms = {'local_stats': round(float(t3[0]), 4), 'exchange_all_reduce': round(float(t3[1]), 4),
+                    'replicated_update': round(float(t3[2]), 4),
+                    'exchange_bytes_per_step': 4 * K_ * W_,
+                    'note': 'per-phase GPU time of one step, max over ranks, synchronised after every step '
+                            '(diagnostic; the timed region above runs without these synchronisations). The '
+                            'all-reduce is fully exposed between the two compute phases: each depends on the '
+                            'other (DESIGN.md section 5).'}
+
     finite = bool(torch.isfinite(Dcur).all().item()) and bool(torch.isfinite(state['x']).all().item())
 
     if rank == 0:
@@ -514,6 +552,8 @@ def main():
             'finite': finite,
             'kernel_ms_avg': {k: round(v['ms_avg'], 4) for k, v in breakdown.items()},
         }
+        if phase_ms is not None:
+            out['phase_ms'] = phase_ms
         # dominant kernel: the fused Y.D^T GEMM + MU quotient (2.N.K.F flop per launch)
         dom = prof.get('x_update')
         traffic, traffic_src = pmc_traffic('0, 0, false, EpiMuNum<float>')
