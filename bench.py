@@ -33,19 +33,25 @@ PEAK_HBM_GBS = 8000.0
 
 
 def synth(n_rows, rank_seed, device):
-    """Y = xt.Dt + 0.1|noise| (>= 0), D0 = max(Dt + 0.3 noise, 0.1): SURVEY 8d, C2.
-    Generated on the GPU (data synthesis only; not part of the measured path)."""
+    """SURVEY 8(d), C2, with np.random.RandomState on the HOST (the generator the CPU and GPU runs share):
+    Dt = max(randn(K, F), 0), xt = max(randn(N, K), 0), Y = xt.Dt + 0.1 |randn| (>= 0),
+    D0 = max(Dt + 0.3 randn, 0.1), float32.  Dt / D0 come from RandomState(1234) on every rank, a rank's rows
+    from RandomState(99 + rank).  Data synthesis only: the product xt.Dt is formed by the host BLAS, the arrays
+    are copied to HBM before anything is timed."""
+    import numpy as np
     import torch
-    g = torch.Generator(device=device)
-    g.manual_seed(1234)                       # Dt / D0 identical on every rank
-    Dt = torch.randn((N_ATOMS, N_FEAT), generator=g, device=device).clamp_(min=0)
-    D0 = (Dt + 0.3 * torch.randn((N_ATOMS, N_FEAT), generator=g, device=device)).clamp_(min=0.1)
-    g.manual_seed(99 + rank_seed)             # this rank's rows
-    xt = torch.randn((n_rows, N_ATOMS), generator=g, device=device).clamp_(min=0)
+    rs = np.random.RandomState(1234)
+    Dt = np.maximum(rs.randn(N_ATOMS, N_FEAT), 0).astype(np.float32)
+    D0 = np.maximum(Dt + 0.3 * rs.randn(N_ATOMS, N_FEAT), 0.1).astype(np.float32)
+    rs = np.random.RandomState(99 + rank_seed)
+    xt = np.maximum(rs.randn(n_rows, N_ATOMS), 0).astype(np.float32)
     Y = xt @ Dt
-    Y += 0.1 * torch.randn((n_rows, N_FEAT), generator=g, device=device).abs_()
     del xt
-    return Y, D0
+    block = 8192                                # noise in row blocks: bounded host temporaries
+    for r0 in range(0, n_rows, block):
+        r1 = min(n_rows, r0 + block)
+        Y[r0:r1] += (0.1 * np.abs(rs.randn(r1 - r0, N_FEAT))).astype(np.float32)
+    return torch.from_numpy(Y).to(device), torch.from_numpy(D0).to(device)
 
 
 def pmc_traffic(kernel_key):
@@ -272,6 +278,16 @@ def secondary_configs(torch, device, with_oracle=False):
         state['count'] += 1
     out['dictionary_step_ms'] = {'workload': 'configs[2] minibatch 8192x4096 k=512 ista x10 fp32',
                                  'value': round(ms_of(dl_step, 6), 4)}
+    def dl_roofline(ms, MB_, F_, K_, iters, cplx):
+        # LASSO (2 N F K + 2 K^2 F + iters 2 N K^2) + x^H x (2 N K^2) + x^H y (2 N K F) + sweep (2 K^2 F)
+        fl = 2.0 * MB_ * F_ * K_ + 2.0 * K_ * K_ * F_ + iters * 2.0 * MB_ * K_ * K_ + 2.0 * MB_ * K_ * K_ + \
+            2.0 * MB_ * K_ * F_ + 2.0 * K_ * K_ * F_
+        if cplx:
+            fl *= 4.0
+        ach = fl / (ms * 1e-3) / 1e12
+        return {'bound': 'mfma', 'scope': 'whole minibatch step (all kernels)', 'flops_per_step': fl,
+                'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS}
+    out['dictionary_step_ms']['roofline'] = dl_roofline(out['dictionary_step_ms']['value'], MB, F, K, 10, False)
     if dl_parity is not None:
         out['dictionary_step_ms']['parity'] = dl_parity
     # the same step with the reference's DEFAULT inner solver (dictionary_learning.py:14, lasso_method='cd'),
@@ -370,6 +386,8 @@ def secondary_configs(torch, device, with_oracle=False):
         cstate['count'] += 1
     out['complex_dictionary_step_ms'] = {'workload': 'configs[4] minibatch 8192x8192 complex64 k=512 ista x10',
                                          'value': round(ms_of(dl_c64, 4), 4)}
+    out['complex_dictionary_step_ms']['roofline'] = dl_roofline(out['complex_dictionary_step_ms']['value'], MB, F, K,
+                                                               10, True)
     if c_parity is not None:
         out['complex_dictionary_step_ms']['parity'] = c_parity
     return out

@@ -102,6 +102,10 @@ SIGNATURES = {
     'dcp_gershgorin_f64': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_gershgorin_c64': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_gershgorin_c128': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_inv_f32': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_inv_f64': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_inv_c64': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_inv_c128': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_calib_read_f32': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_int, _c_vp]),
     'dcp_gemm_c64': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                               _c_int, _c_int]),

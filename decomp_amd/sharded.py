@@ -243,7 +243,9 @@ def dict_loop(backend, y_local, x_local, row0, n_total, D, tol, minibatch, maxit
 
     Deviations from the single-process run, both at rounding / tolerance level: the statistics are
     summed in a different order; the LASSO's early exit (|dx| < lasso_tol on iterations 0, 10, ...,
-    lasso.py:293) is taken per rank on its own rows instead of on the whole minibatch.
+    lasso.py:293) is taken per rank on its own rows instead of on the whole minibatch, so when it fires
+    on one rank and not on another the codes differ by what the remaining iterations would have moved
+    them, i.e. by O(lasso_tol) (tests/test_gpu_dictionary.py::test_sharded_dictionary_early_exit_per_rank).
     Returns (it, D, x_local)."""
     import torch.distributed as dist
     import numpy as np
@@ -268,11 +270,16 @@ def dict_loop(backend, y_local, x_local, row0, n_total, D, tol, minibatch, maxit
     for it in range(1, maxiter):
         rng.shuffle(index)                      # dictionary_learning.py:131-133
         order = order[index]
+        # this rank's members of every minibatch of the epoch: ONE index upload per epoch, sliced on the device
+        mines = []
         for m in range(n_loop):
             rows = order[m * minibatch:(m + 1) * minibatch]
-            mine = rows[(rows >= row0) & (rows < row0 + n_local)] - row0
-            n = int(mine.shape[0])
-            idx = index_to_device(mine) if n else None
+            mines.append(rows[(rows >= row0) & (rows < row0 + n_local)] - row0)
+        offs = np.concatenate([[0], np.cumsum([len(v) for v in mines])]).astype(np.int64)
+        idx_all = index_to_device(np.concatenate(mines)) if offs[-1] else None
+        for m in range(n_loop):
+            n = int(offs[m + 1] - offs[m])
+            idx = idx_all[int(offs[m]):int(offs[m + 1])] if n else None
             backend.gather(y_local, idx, n, y_stage)
             backend.gather(x_local, idx, n, x_stage)
             if n:

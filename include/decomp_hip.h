@@ -109,6 +109,15 @@ int dcp_gershgorin_f64(dcp_handle* h, const double* X, int64_t batch, int64_t n,
 int dcp_gershgorin_c64(dcp_handle* h, const void* X, int64_t batch, int64_t n, float* out);
 int dcp_gershgorin_c128(dcp_handle* h, const void* X, int64_t batch, int64_t n, double* out);
 
+/* math_utils/linalg.py:9-38 (inv, "batch version of np.linalg.inv"): out[b] = X[b]^-1 for a batch
+ * X[batch, n, n]; Gauss-Jordan with partial pivoting, computed in double precision (complex double) whatever
+ * the storage dtype, one workgroup per matrix.  A singular matrix yields inf / nan entries (NumPy raises
+ * LinAlgError).  X and out must not overlap.  Asynchronous on the handle's stream. */
+int dcp_inv_f32(dcp_handle* h, const float* X, int64_t batch, int64_t n, float* out);
+int dcp_inv_f64(dcp_handle* h, const double* X, int64_t batch, int64_t n, double* out);
+int dcp_inv_c64(dcp_handle* h, const void* X, int64_t batch, int64_t n, void* out);
+int dcp_inv_c128(dcp_handle* h, const void* X, int64_t batch, int64_t n, void* out);
+
 /* Test hook (not a reference interface): C[M,N] = op(A) . op(B) through the same GEMM
  * cores the solvers use.  form: 0 = NT (A[M,K], B[N,K]), 1 = NN (A[M,K], B[K,N]),
  * 2 = TN (A[K,M], B[K,N]).  ksplits >= 1 selects split-K (partials summed in order).

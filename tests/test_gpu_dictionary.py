@@ -307,7 +307,7 @@ def test_sharded_dictionary_world1_equals_solve():
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
-def _dl_gloo_gpu_worker(rank, world, port, q):
+def _dl_gloo_gpu_worker(rank, world, port, q, kw=None):
     import os
     import sys
     import torch.distributed as dist
@@ -326,7 +326,7 @@ def _dl_gloo_gpu_worker(rank, world, port, q):
             calls['n'] += 1
             return real(*a, **k)
         dist.all_reduce = counting
-        it, D, x = sharded.dictionary_learning_sharded(y[lo:hi].copy(), D0.copy(), 0.02, **_DL_KW)
+        it, D, x = sharded.dictionary_learning_sharded(y[lo:hi].copy(), D0.copy(), 0.02, **(kw or _DL_KW))
         q.put((rank, it, D, x, calls['n']))
     finally:
         dist.destroy_process_group()
@@ -358,3 +358,35 @@ def test_sharded_dictionary_two_ranks_on_one_gpu_gloo():
     assert _err(res[0][2], D1) < 1e-4 and _err(x_all, x1) < 1e-3
     n_steps = (_DL_KW['maxiter'] - 1) * (y.shape[0] // _DL_KW['minibatch'])
     assert res[0][4] == res[1][4] == n_steps                          # exactly one collective per step
+
+
+def test_sharded_dictionary_early_exit_per_rank():
+    """with a LOOSE lasso_tol the LASSO's early exit (lasso.py:293, checked on iterations 0, 10, ...)
+    fires, and in the sharded run it is taken per rank on the rows that rank owns.  The two-rank result must
+    stay within O(lasso_tol) of the single-process one (codes) and the replicated D must still be bit-identical
+    across ranks; the single-process run with the same settings really does stop early (its codes differ from
+    a run that is forced through all iterations)."""
+    import os
+    import torch.multiprocessing as mp
+    from decomp_amd import dictionary_learning as dl
+    y, D0 = _sharded_dl_problem()
+    lasso_tol = 0.05
+    kw = dict(_DL_KW, lasso_iter=41, lasso_tol=lasso_tol)
+    it1, D1, x1 = dl.solve(y.copy(), D0.copy(), 0.02, **kw)
+    itf, Df, xf = dl.solve(y.copy(), D0.copy(), 0.02, **dict(kw, lasso_tol=0.0))
+    assert np.max(np.abs(x1 - xf)) > 0                                  # the early exit was taken
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 28800 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_dl_gloo_gpu_worker, args=(r, 2, port, q, kw)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == it1
+    assert np.array_equal(res[0][2], res[1][2])                         # replicated D: bit-identical
+    x_all = np.concatenate([res[0][3], res[1][3]], axis=0)
+    assert np.max(np.abs(x_all - x1)) <= 20 * lasso_tol                 # O(lasso_tol), codes are O(3)
+    assert _err(res[0][2], D1) < 0.1

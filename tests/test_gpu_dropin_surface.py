@@ -324,3 +324,30 @@ def test_subclass_of_builtin_overriding_one_method():
         ito, Do, xo = onmf.solve(y, D0.copy(), tol=0.0, maxiter=12, likelihood='kl', mask=m)
         it, D, x = decomp.nmf.solve(y, D0.copy(), tol=0.0, maxiter=12, likelihood=KlOnlyGradD(), mask=m)
         assert it == ito == 12 and np.max(np.abs(D - Do)) < 1e-9
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32, np.complex128, np.complex64])
+def test_linalg_inv_matches_numpy(dtype):
+    """math_utils.linalg.inv (linalg.py:9-38): 2-D and batched (3-, 4-D) inputs against np.linalg.inv, incl. a
+    matrix that needs row pivoting (zero leading entry) and the ADMM system A A^H + rho I."""
+    import torch
+    from decomp_amd.math_utils import linalg
+    rng = np.random.RandomState(21)
+    cplx = np.dtype(dtype).kind == 'c'
+
+    def randn(*s):
+        return ((rng.randn(*s) + 1j * rng.randn(*s)) if cplx else rng.randn(*s)).astype(dtype)
+    tol = 2e-4 if dtype in (np.float32, np.complex64) else 1e-10
+    for shape in [(7, 7), (3, 33, 33), (2, 3, 12, 12), (1, 1), (130, 130)]:
+        x = randn(*shape)
+        if shape == (7, 7):
+            x[0, 0] = 0                                     # forces a row exchange in the first step
+        got = linalg.inv(x)
+        want = np.linalg.inv(x.astype(np.complex128 if cplx else np.float64))
+        assert isinstance(got, np.ndarray) and got.dtype == dtype and got.shape == x.shape
+        assert np.max(np.abs(got - want)) <= tol * max(1.0, np.max(np.abs(want))), shape
+    A = randn(40, 90)
+    S = A @ np.conj(A.T) + 1.0 * np.eye(40)
+    got = linalg.inv(torch.from_numpy(S.astype(dtype)).cuda())
+    assert got.is_cuda
+    assert np.max(np.abs(got.cpu().numpy() @ S - np.eye(40))) < (5e-3 if tol > 1e-6 else 1e-9)
