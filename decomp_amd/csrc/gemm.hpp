@@ -162,6 +162,8 @@ typedef TileCfg<32, 128, 32, 32, 32, 2> CfgFlat;       // <= 32 output rows (x^T
 typedef TileCfg<128, 32, 32, 32, 32, 2> CfgTall;       // <= 32 output columns (Y.D^T, x.G with <= 32 atoms)
 typedef TileCfg<256, 256, 32, 64, 64, 1> CfgHugeDeep;   // 16 waves, 32-deep K blocks (128 KiB LDS): x^T [y|x] with >= 512
                                                       // atoms (dictionary step, 512 x 4608 x 8192, 7 splits: 0.362 -> 0.328 ms)
+typedef TileCfg<128, 128, 16, 64, 64, 2, 3> CfgLargeX;       // the pair schedule (PIPE = 3) for row-contiguous panels
+typedef TileCfg<256, 256, 32, 64, 64, 1, 3> CfgHugeDeepX;
 typedef TileCfg<64, 64, 64, 32, 32, 1> CfgSmallDeep;   // 64 KiB LDS: latency-bound products on few CUs (64-row
                                                       // atom-block GEMMs): 4x fewer, 4x larger K blocks in flight
 
@@ -364,6 +366,8 @@ inline int plan_deep_nt(GemmArgs<T>& a, int max_s) {
     return a.ksplits;
 }
 
+inline bool tn_plain_schedule() { return getenv("DCP_TN_PLAIN") != nullptr; }
+
 template <int FORM, class T, class Epi>
 inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi) {
     if constexpr (std::is_same<T, float>::value) {
@@ -389,6 +393,13 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
         }
         if (tier == TIER_SMALL) return launch_gemm_mfma<CfgSmall, AL, BL, Epi>(stream, p, epi);
         if (tier == TIER_SMALL_DEEP) return launch_gemm_mfma<CfgSmallDeep, AL, BL, Epi>(stream, p, epi);
+        if constexpr (FORM == FORM_TN && (epi_mode<Epi>::value == 0)) {
+            // reduction over samples, both panels row-contiguous: the pair schedule (DCP_TN_PLAIN=1: A/B knob)
+            if (!tn_plain_schedule()) {
+                if (tier == TIER_HUGE_DEEP) return launch_gemm_mfma<CfgHugeDeepX, AL, BL, Epi>(stream, p, epi);
+                if (tier == TIER_LARGE) return launch_gemm_mfma<CfgLargeX, AL, BL, Epi>(stream, p, epi);
+            }
+        }
         if (tier == TIER_HUGE_DEEP) return launch_gemm_mfma<CfgHugeDeep, AL, BL, Epi>(stream, p, epi);
         if (tier == TIER_FLAT) return launch_gemm_mfma<CfgFlat, AL, BL, Epi>(stream, p, epi);
         if (tier == TIER_TALL) return launch_gemm_mfma<CfgTall, AL, BL, Epi>(stream, p, epi);
@@ -420,6 +431,7 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     const int tier = pick_tier<FORM>(p.M, p.N, p.K, a.tile, a.split_planned);
                     if (tier == TIER_SMALL || tier == TIER_SMALL_DEEP || tier == TIER_FLAT || tier == TIER_TALL)
                         return launch_gemm_mfma<CfgSmall, AL, BL>(stream, p, ce);
+                    if (!tn_plain_schedule()) return launch_gemm_mfma<CfgLargeX, AL, BL>(stream, p, ce);
                     return launch_gemm_mfma<CfgLarge, AL, BL>(stream, p, ce);
                 } else if (cplx_planar_a<FORM>(a.M, a.N, a.conjA, a.conjB, a.ext_ws)) {
                     // rows(A): [2M, K] real image in the caller's scratch (2MK <= 4KN reals); B as it lies
@@ -585,6 +597,16 @@ struct EpiSlab {  // split-K partial: slab[split][row, col] = acc
     bool vec_ok() const { return al16_ptr(slab) && (ldc % 4) == 0 && (slab_stride % 4) == 0; }
     __device__ __forceinline__ void vec4(int r, int c0, f32x4 v, int s) const {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(slab) + (long)s * slab_stride + (long)r * ldc + c0) = v;
+    }
+    // pair schedule of the fp32 MFMA core (TileCfg PIPE = 3): two adjacent columns in one 8-byte store
+    static constexpr bool kVec2 = std::is_same<T, float>::value;
+    bool vec2_ok() const {
+        return (reinterpret_cast<uintptr_t>(slab) & 7) == 0 && (ldc % 2) == 0 && (slab_stride % 2) == 0;
+    }
+    __device__ __forceinline__ void store2(int r, int c0, float v0, float v1, int s) const {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2*>(reinterpret_cast<float*>(slab) + (long)s * slab_stride + (long)r * ldc + c0) =
+            f32x2{v0, v1};
     }
 };
 

@@ -68,6 +68,14 @@ struct GemmProblem {
 // PIPE_ = 1: the per-block barrier sits between the MFMA groups of a K block (operands of the
 // last group already in registers, first group of the next block prefetched right after the
 // barrier), so no wave leaves the barrier with nothing to feed the matrix pipe.
+// PIPE_ = 3 (both panels row-contiguous, i.e. the reduction-over-samples form, 64 x 64 wave tiles): the
+// "pair" schedule.  A lane reads TWO adjacent rows of a panel line with one ds_read_b64 (256 B/clk, against
+// 128 B/clk for the ds_read2_b32 pairs the plain schedule compiles to) and owns the interleaved rows
+// 2 l + i / columns 2 l + j of the wave tile instead of l + 32 i / l + 32 j; MFMA step s takes k = 2 s + h.
+// Fragment reads run TWO steps ahead of the MFMAs that consume them (the plain schedule reads a step's
+// operands and waits for them right before its four MFMAs: one exposed LDS round trip per step).  The
+// epilogue stores the two adjacent columns of a lane with one 8-byte store; complex products (mode 2) find
+// the whole 2 x 2 real block of a complex output in ONE lane: no shuffles, every lane stores.
 // MF_ = 32: v_mfma_f32_32x32x2_f32; MF_ = 16: v_mfma_f32_16x16x4_f32 (same flop rate, same LDS
 // read volume and accumulator count; the chip may hold a different clock on it, guide rule 28).
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int PIPE_ = 0, int MF_ = 32>
@@ -118,6 +126,19 @@ template <class E, class = void>
 struct epi_vec4 { static constexpr bool value = false; };
 template <class E>
 struct epi_vec4<E, decltype((void)E::kVec4)> { static constexpr bool value = E::kVec4; };
+
+// Pair-schedule functors may carry `static constexpr bool kVec2 = true` with
+//     bool vec2_ok() const                                   (host: base 8-byte aligned, leading dims even)
+//     void store2(int row, int col0, float v0, float v1, int split) const     (columns col0, col0 + 1; col0 even)
+template <class E, class = void>
+struct epi_vec2 { static constexpr bool value = false; };
+template <class E>
+struct epi_vec2<E, decltype((void)E::kVec2)> { static constexpr bool value = E::kVec2; };
+template <class E>
+inline bool epi_vec2_ok(const E& e) {
+    if constexpr (epi_vec2<E>::value) return e.vec2_ok();
+    else return false;
+}
 
 template <class E>
 inline bool epi_vec_ok(const E& e) {
@@ -279,6 +300,45 @@ __device__ __forceinline__ f32x4 panel_frag16(const float* s, int row, int q) {
         return v;
     }
 }
+
+// ---- pair schedule (TileCfg PIPE = 3): hand-placed LDS reads ---------------------------------------------
+// hipcc merges adjacent 8-byte LDS reads into ds_read2st64_b64 (32-bank mode: lanes l and l + 16 collide) and
+// parks every read directly in front of its consumers behind s_waitcnt lgkmcnt(0), whatever the source order
+// says; so the fragment reads are inline asm (plain ds_read_b64, 64-bank mode, conflict free for 64
+// consecutive dwords per half wave) and the counted waits are ours (guide 5.7 item 1, form ii: the wait
+// statement names the destinations "+v", which keeps their consumers behind it).
+typedef float pair_f32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void lds_read_b64_at(pair_f32x2& d, unsigned lds_addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(lds_addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_pair(pair_f32x2& a, pair_f32x2& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
+}
+__device__ __forceinline__ unsigned lds_addr_of(const float* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p;
+}
+// steps ST .. NS-1 of one K block: operands of step ST + 2 are requested before the MFMAs of step ST issue
+template <int ST, int NS, int ASTEP_BYTES, int BSTEP_BYTES>
+struct PairSteps {
+    __device__ static __forceinline__ void run(f32x16 (&acc)[2][2], pair_f32x2& a0, pair_f32x2& b0, pair_f32x2& a1,
+                                               pair_f32x2& b1, unsigned aaddr, unsigned baddr) {
+        pair_f32x2 a2 = a1, b2 = b1;
+        if constexpr (ST + 2 < NS) {
+            lds_read_b64_at<(ST + 2) * ASTEP_BYTES>(a2, aaddr);
+            lds_read_b64_at<(ST + 2) * BSTEP_BYTES>(b2, baddr);
+        }
+        // reads issued after those of step ST: two steps' worth, less at the end of the block
+        constexpr int NEWER = (ST + 2 < NS) ? 4 : ((ST + 1 < NS) ? 2 : 0);
+        lds_wait_pair<NEWER>(a0, b0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0[0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0[1], acc[1][1], 0, 0, 0);
+        if constexpr (ST + 1 < NS) PairSteps<ST + 1, NS, ASTEP_BYTES, BSTEP_BYTES>::run(acc, a1, b1, a2, b2, aaddr, baddr);
+    }
+};
 
 template <class Cfg, int ALAY, int BLAY, bool EDGE, class Epi>
 __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(GemmProblem p, Epi epi) {
@@ -495,6 +555,32 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
             }
             __syncthreads();
         }
+    } else if constexpr (Cfg::PIPE == 3) {
+        static_assert(ALAY == XMAJOR && BLAY == XMAJOR && TM == 2 && TN == 2, "pair schedule: row-contiguous panels, 64 x 64 wave tiles");
+        static_assert(!ROWBITS, "pair schedule: no row-bit epilogues");
+        constexpr int NS = BK / 2;
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int cur = kb & 1;
+            const unsigned aaddr = lds_addr_of(sA0 + cur * GA::ELEMS + h * GA::STRIDE + wm * WM + 2 * l31);
+            const unsigned baddr = lds_addr_of(sB0 + cur * GB::ELEMS + h * GB::STRIDE + wn * WN + 2 * l31);
+            const bool more = (kb + 1) < nkb;
+            if (more) {
+                const int k0 = kbeg + (kb + 1) * BK;
+                panel_gload<ALAY, BM, BK, EDGE, NT>(ra, Ap, lda, mA0, nArows, k0, kend, tid, a_al && (k0) + BK <= kend);
+                panel_gload<BLAY, BN, BK, EDGE, NT>(rb, Bp, ldb, nB0, nBrows, k0, kend, tid, b_al && (k0) + BK <= kend);
+            }
+            pair_f32x2 a0, b0, a1, b1;
+            lds_read_b64_at<0>(a0, aaddr);
+            lds_read_b64_at<0>(b0, baddr);
+            lds_read_b64_at<2 * GA::STRIDE * 4>(a1, aaddr);
+            lds_read_b64_at<2 * GB::STRIDE * 4>(b1, baddr);
+            PairSteps<0, NS, 2 * GA::STRIDE * 4, 2 * GB::STRIDE * 4>::run(acc, a0, b0, a1, b1, aaddr, baddr);
+            if (more) {
+                panel_lds_store<ALAY, BM, BK, NT, MF>(sA0 + (cur ^ 1) * GA::ELEMS, ra, tid);
+                panel_lds_store<BLAY, BN, BK, NT, MF>(sB0 + (cur ^ 1) * GB::ELEMS, rb, tid);
+            }
+            __syncthreads();
+        }
     } else if constexpr (Cfg::PIPE == 0) {
         for (int kb = 0; kb < nkb; ++kb) {
             const int cur = kb & 1;
@@ -614,6 +700,41 @@ __global__ void __launch_bounds__(Cfg::NTHREADS, Cfg::MINW) gemm_mfma_kernel(Gem
     //   3  complex x y with the planar rows of x against the real view of y: the same 2x2 block,
     //      re = rr - ii, im = ri + ir
     constexpr int MODE = epi_mode<Epi>::value;
+    if constexpr (Cfg::PIPE == 3) {
+        // pair schedule: accumulator (i, j) register r of lane (l31, h) is output row 2 rin + i, column 2 l31 + j
+        static_assert(MODE == 0 || MODE == 2, "pair schedule: real outputs or the complex x^H y combination");
+        const int rbase = m0 + wm * WM, cbase = n0 + wn * WN + 2 * l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rin = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rbase + 2 * rin + i;
+                    const float v0 = acc[i][0][r], v1 = acc[i][1][r];
+                    if (!EDGE || (row < p.M && cbase + 1 < ncol_end)) {
+                        if constexpr (epi_vec2<Epi>::value) {
+                            if (p.vec_epi) epi.store2(row, cbase, v0, v1, split);
+                            else { epi(row, cbase, v0, split); epi(row, cbase + 1, v1, split); }
+                        } else {
+                            epi(row, cbase, v0, split);
+                            epi(row, cbase + 1, v1, split);
+                        }
+                    } else if (row < p.M && cbase < ncol_end) {
+                        epi(row, cbase, v0, split);
+                    }
+                }
+            } else {
+                // rows 2 m, 2 m + 1 = (re, im) of x column m, columns 2 n, 2 n + 1 = (re, im) of y column n:
+                // (rr ri; ir ii) = (acc00 acc01; acc10 acc11);  x^H y: re = rr + ii, im = ri - ir
+                const float re = acc[0][0][r] + acc[1][1][r];
+                const float im = acc[0][1][r] - acc[1][0][r];
+                const int row = rbase + 2 * rin;
+                if (!EDGE || (row + 1 < p.M && cbase + 1 < ncol_end)) epi.pair(row >> 1, cbase >> 1, re, im, split);
+            }
+        }
+        return;
+    }
     if constexpr ((MODE == 0 || MODE == 1) && !EDGE && !ROWBITS && epi_vec4<Epi>::value) {
         if (p.vec_epi) {
             const int t = l31 & 3, col0 = (l31 & ~3);
@@ -717,6 +838,11 @@ inline hipError_t launch_gemm_mfma(hipStream_t stream, GemmProblem p, const Epi&
     if (p.B2 != nullptr) fast = fast && (p.n_b1 % BN == 0) && (p.ldb2 % 4 == 0) && al16(p.B2);
     if (p.A2 != nullptr) fast = fast && (p.m_a1 % BM == 0) && (p.lda2 % 4 == 0) && al16(p.A2);
     p.vec_epi = (fast && epi_vec_ok(epi)) ? 1 : 0;
+    if constexpr (Cfg::PIPE == 3) {
+        // pair schedule: vec_epi = the functor's 8-byte store of two adjacent columns may be used (every
+        // column origin of a lane is even: segment seams and leading dims even, base 8-byte aligned)
+        p.vec_epi = (epi_vec2_ok(epi) && (p.n_b1 % 2) == 0) ? 1 : 0;
+    }
     p.al_mask = ((al16(p.A) && p.lda % 4 == 0) ? 1 : 0) | ((p.A2 != nullptr && al16(p.A2) && p.lda2 % 4 == 0) ? 2 : 0) |
                 ((al16(p.B) && p.ldb % 4 == 0) ? 4 : 0) | ((p.B2 != nullptr && al16(p.B2) && p.ldb2 % 4 == 0) ? 8 : 0);
     const int grid = p.tiles_m * p.tiles_n * p.ksplits;
