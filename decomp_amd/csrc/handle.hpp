@@ -25,6 +25,7 @@ struct dcp_handle {
     // ordered against the main stream with events only (side_after_main / main_after_side).
     hipStream_t side = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    hipEvent_t ev_flag = nullptr;   // behind the stop-flag copy of a LASSO check iteration (read one iteration late)
     // Workspace: one grow-only arena.  A public call plans its total need, reserves it
     // (ws_reserve: reallocates only when the plan outgrows the arena, i.e. on the first
     // call of a given problem size, never in steady state), then bumps (ws_alloc).

@@ -241,6 +241,18 @@ __global__ void __launch_bounds__(256) gershgorin_finish_kernel(const R* __restr
         // dependent L2 round trips (measured 31 us at K = 512 for 128 KiB of partials)
         R a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         int s = 0;
+        for (; s + 15 < stripes; s += 16) {   // sixteen loads in flight, same four interleaved sums
+            R v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(long)(s + u) * K + j];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                a0 += v[u];
+                a1 += v[u + 1];
+                a2 += v[u + 2];
+                a3 += v[u + 3];
+            }
+        }
         for (; s + 3 < stripes; s += 4) {
             a0 += partial[(long)s * K + j];
             a1 += partial[(long)(s + 1) * K + j];
@@ -1019,6 +1031,27 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         T* lastNw = xcur;
         double beta = 1.0;
         bool converged = false;
+        // The stop test of a check iteration (i % 10 == 0, lasso.py:293) is read ONE iteration late: its flag
+        // travels to the host behind an event while iteration i + 1 is already enqueued, so the GPU does not
+        // idle through a host round trip in the middle of every solve (the dictionary step runs ten
+        // iterations and checks at i = 0).  Iteration i + 1 only READS iteration i's output, so when the test
+        // had passed that output is still intact and i + 1 is simply discarded.
+        if (h->ev_flag == nullptr) DCP_HIP_OK(h, hipEventCreateWithFlags(&h->ev_flag, hipEventDisableTiming));
+        int pend_i = -1;
+        T* pend_x = nullptr;
+        auto resolve = [&](bool* stop) -> int {
+            *stop = false;
+            if (pend_i < 0) return DCP_OK;
+            DCP_HIP_OK(h, hipEventSynchronize(h->ev_flag));
+            if (*host_flag == 0) {
+                it = pend_i;
+                result = pend_x;
+                converged = true;
+                *stop = true;
+            }
+            pend_i = -1;
+            return DCP_OK;
+        };
         for (int i = 0; i < maxiter; ++i) {
             T* Nw = nullptr;
             T* Vn = nullptr;
@@ -1040,6 +1073,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             if (check) DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
             EpiProxStep<T, PROX> epi{w.yAt, V, P, Nw, mom ? Vn : (T*)nullptr, (long)K, w.scal,
                                      w.alphak, w.tolk, rowscale, coef, check, w.flag};
+            const bool had_pending = pend_i >= 0;
             if (mask_ndim == 2) {
                 GemmArgs<T> a1;   // T1 = (V An) o M
                 a1.A = V; a1.lda = K; a1.B = w.An; a1.ldb = F; a1.M = N; a1.N = F; a1.K = K;
@@ -1056,16 +1090,26 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
                 a.ext_ws = w.ext2;
                 DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, epi)));
             }
+            if (had_pending) {   // the check iteration before this one: was its test met?  (lasso.py:293-294)
+                bool stop = false;
+                DCP_TRY(resolve(&stop));
+                if (stop) break;   // this iteration is discarded
+            }
             if (check) {
-                bool viol = true;
-                DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
-                if (!viol) { it = i; result = Nw; converged = true; break; }   // lasso.py:293-294
+                DCP_HIP_OK(h, hipMemcpyAsync(host_flag, w.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+                DCP_HIP_OK(h, hipEventRecord(h->ev_flag, st));
+                pend_i = i;
+                pend_x = Nw;
             }
             lastP = P;
             lastNw = Nw;
             P = Nw;
             V = mom ? Vn : Nw;
             beta = beta_new;
+        }
+        if (!converged) {   // a check on the very last iteration
+            bool stop = false;
+            DCP_TRY(resolve(&stop));
         }
         // QUIRK: on exhaustion ista / fista return the latest iterate, acc_ista the one
         // before it (its `x0 = x0_new` sits at the top of the loop body, lasso.py:351-357).
