@@ -40,6 +40,9 @@ struct GemmArgs {
     // complex only: scratch for the real "extended" image of B (4 * rows(B) * cols(B) reals).
     // With it NT / NN products run on the fp32 / fp64 MFMA core; TN needs none.  Null -> generic core.
     real_t<T>* ext_ws = nullptr;
+    // complex only: ext_ws ALREADY holds the extended image of this B (same B, same form family) from an
+    // earlier product of the caller -- the ten ISTA iterations of a solve multiply by the same A A^H
+    bool ext_ready = false;
     // complex64 NN only: the planar-rows image of A ([2M, K] reals, leading dim lda_rows) when the caller
     // already holds it (the atom sweep prepares its block matrices that way once per sweep)
     const real_t<T>* A_rows = nullptr;
@@ -461,8 +464,9 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     long g = (rowsB * colsB + 255) / 256;
                     if (g > 4096) g = 4096;
                     if (g < 1) g = 1;
-                    hipLaunchKernelGGL((cplx_ext_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, a.B,
-                                       rowsB, colsB, a.ldb, a.ext_ws);
+                    if (!a.ext_ready)
+                        hipLaunchKernelGGL((cplx_ext_kernel<float>), dim3((unsigned)g), dim3(256), 0, stream, a.B,
+                                           rowsB, colsB, a.ldb, a.ext_ws);
                     p.B = a.ext_ws; p.ldb = 2 * colsB;
                     p.M = a.M; p.N = 2 * a.N; p.K = 2 * a.K;
                     if (a.ksplits <= 1) p.klen = 0;
@@ -522,8 +526,9 @@ inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi)
                     long g = (rowsB * colsB + 255) / 256;
                     if (g > 4096) g = 4096;
                     if (g < 1) g = 1;
-                    hipLaunchKernelGGL((cplx_ext_kernel<double>), dim3((unsigned)g), dim3(256), 0, stream, a.B,
-                                       rowsB, colsB, a.ldb, a.ext_ws);
+                    if (!a.ext_ready)
+                        hipLaunchKernelGGL((cplx_ext_kernel<double>), dim3((unsigned)g), dim3(256), 0, stream, a.B,
+                                           rowsB, colsB, a.ldb, a.ext_ws);
                     p.B = a.ext_ws; p.ldb = 2 * colsB;
                     p.M = a.M; p.N = 2 * a.N; p.K = 2 * a.K;
                     if (a.ksplits <= 1) p.klen = 0;

@@ -1088,6 +1088,10 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
                 GemmArgs<T> a;    // back = V AAt, prox step in the epilogue
                 a.A = V; a.lda = K; a.B = w.AAt; a.ldb = K; a.M = N; a.N = K; a.K = K;
                 a.ext_ws = w.ext2;
+                // complex: the extended image of A A^H (ext2 holds nothing else during the loop) is built by
+                // the first iteration and reused by the others (a product with fewer samples than atoms takes
+                // the planar-rows form instead, which images V and ignores this flag)
+                a.ext_ready = i > 0 && !cplx_planar_a<FORM_NN>(N, K, false, false, w.ext2);
                 DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, epi)));
             }
             if (had_pending) {   // the check iteration before this one: was its test met?  (lasso.py:293-294)
