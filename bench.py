@@ -70,7 +70,11 @@ def pmc_traffic(kernel_key):
         d = json.load(open(files[-1]))
         for k, v in d.items():
             if kernel_key in k and 'hbm_bytes_corrected' in v:
-                return v['hbm_bytes_corrected'], 'from %s (N=1 run)' % os.path.basename(files[-1])
+                return v['hbm_bytes_corrected'], ('from %s (N=1 run; FETCH_SIZE x %.2f as calibrated for this loader, '
+                                                  'profiles/r01_fetch_calibration.txt; with the guide\'s x2 for wide '
+                                                  'reads: %.4g B)' % (os.path.basename(files[-1]),
+                                                                     v.get('fetch_correction_factor', 2.0),
+                                                                     v.get('hbm_bytes_guide_x2', float('nan'))))
     except Exception as e:  # pragma: no cover
         return None, 'unreadable PMC summary: %s' % e
     return None, 'kernel not in PMC summary'
