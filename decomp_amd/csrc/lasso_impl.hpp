@@ -297,14 +297,18 @@ __global__ void __launch_bounds__(256) vec_sum_kernel(const R* __restrict__ v, l
 // (g -= dx AAt[k, :], one coalesced row read) and the lanes behind it are re-evaluated.  The
 // sequence of applied updates is exactly that of the sequential sweep (lasso.py:539-548); with
 // sparse codes a sweep costs ~(#changed coordinates) steps instead of K.
-// Sweeps [.., + nsweeps); the LAST one is a check sweep when check_last != 0.
+// Sweeps [.., + nsweeps); the FIRST one is a check sweep when check_first != 0 (the reference tests on
+// sweeps 0, 10, 20, ...: a launch starts at one and runs on through the nine after it).  `snap` (nullable):
+// the codes as they stand after that first sweep -- what the reference returns when the test passes there
+// (lasso.py:546-551); the host reads the flag after the launch and takes the snapshot instead of the
+// result of the extra sweeps, so a solve costs one launch and one host round trip per ten sweeps.
 template <class T, int PROX, int MAXM>
 __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __restrict__ G,
                                                       const T* __restrict__ AAt,
                                                       const real_t<T>* __restrict__ alphak,
                                                       const real_t<T>* __restrict__ tolk, long rows,
-                                                      int K, int nsweeps, int check_last,
-                                                      int* __restrict__ flag) {
+                                                      int K, int nsweeps, int check_first,
+                                                      int* __restrict__ flag, T* __restrict__ snap) {
     typedef real_t<T> R;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -329,7 +333,14 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
     }
     bool viol = false;
     for (int s = 0; s < nsweeps; ++s) {
-        const bool check = check_last && (s == nsweeps - 1);
+        const bool check = check_first && (s == 0);
+        if (s == 1 && snap != nullptr) {   // the codes after the check sweep
+#pragma unroll
+            for (int m = 0; m < MAXM; ++m) {
+                const int c = lane + 64 * m;
+                if (m < M && c < K) snap[row * K + c] = x[m];
+            }
+        }
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) {
             if (m >= M) break;
@@ -399,8 +410,8 @@ __global__ void __launch_bounds__(256) cd_gram_wide_kernel(T* __restrict__ X, T*
                                                            const T* __restrict__ AAt,
                                                            const real_t<T>* __restrict__ alphak,
                                                            const real_t<T>* __restrict__ tolk, long rows,
-                                                           int K, int nsweeps, int check_last,
-                                                           int* __restrict__ flag) {
+                                                           int K, int nsweeps, int check_first,
+                                                           int* __restrict__ flag, T* __restrict__ snap) {
     typedef real_t<T> R;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -410,7 +421,9 @@ __global__ void __launch_bounds__(256) cd_gram_wide_kernel(T* __restrict__ X, T*
     T* grow = G + row * K;
     bool viol = false;
     for (int s = 0; s < nsweeps; ++s) {
-        const bool check = check_last && (s == nsweeps - 1);
+        const bool check = check_first && (s == 0);
+        if (s == 1 && snap != nullptr)     // the codes after the check sweep (see cd_gram_kernel)
+            for (int c = lane; c < K; c += 64) snap[row * K + c] = xrow[c];
         for (int m = 0; m < M; ++m) {
             const int c0 = lane + 64 * m;
             const bool ok = c0 < K;
@@ -933,19 +946,24 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             a.ext_ws = w.ext2;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiSubFrom<T>{w.yAt, K, w.G, K})));
         }
+        // One launch = a check sweep (0, 10, 20, ...: lasso.py:546-551) and the up to nine sweeps after it; the
+        // codes after the check sweep are parked in a snapshot, the flag is read after the launch: when the test
+        // had passed, the snapshot is the answer and the extra sweeps (nearly free on converged codes: every
+        // step is a skipped zero step) are dropped.  Before: two launches and a host round trip per ten sweeps.
+        T* snap_buf = w.xb[1];
         int sweep = 0;
+        result = xcur;
         while (sweep < maxiter) {
-            // run up to and including the next check sweep (sweeps 0, 10, 20, ...)
-            int last = (sweep % 10 == 0) ? sweep : (sweep / 10 + 1) * 10;
-            int check_last = 1;
-            if (last > maxiter - 1) { last = maxiter - 1; check_last = (last % 10 == 0); }
+            int last = sweep + 9;
+            if (last > maxiter - 1) last = maxiter - 1;
             const int ns = last - sweep + 1;
+            T* snap = ns > 1 ? snap_buf : (T*)nullptr;
             DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
             const int grid = (N + 3) / 4;
 #define DCP_CD_LAUNCH(MM)                                                                            \
     hipLaunchKernelGGL((cd_gram_kernel<T, PROX, MM>), dim3(grid), dim3(256), 0, st, xcur, w.G,       \
-                       (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,        \
-                       check_last, w.flag)
+                       (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns, 1,     \
+                       w.flag, snap)
             // (the register form holds a row's K coefficients in one wave: 64 lanes x up to 32 slots;
             //  wider dictionaries take the memory-resident form -- the reference has no limit, lasso.py:526-552)
             if (K <= 64) DCP_CD_LAUNCH(1);
@@ -956,18 +974,19 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             else if (K <= cd_register_limit()) DCP_CD_LAUNCH(32);
             else
                 hipLaunchKernelGGL((cd_gram_wide_kernel<T, PROX>), dim3(grid), dim3(256), 0, st, xcur, w.G,
-                                   (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,
-                                   check_last, w.flag);
+                                   (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns, 1,
+                                   w.flag, snap);
 #undef DCP_CD_LAUNCH
             DCP_LAUNCH_OK(h, hipGetLastError());
-            sweep = last + 1;
-            if (check_last) {
-                bool viol = true;
-                DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
-                if (!viol) { it = last; break; }
+            bool viol = true;
+            DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
+            if (!viol) {
+                it = sweep;
+                result = snap != nullptr ? snap : xcur;
+                break;
             }
+            sweep = last + 1;
         }
-        result = xcur;
     } else if (method == DCP_LASSO_CD) {
         // ---------------- coordinate descent with a 2-D mask (as written) ----------------
         {   // r = y o M - (x An) o M
