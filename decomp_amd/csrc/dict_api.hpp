@@ -64,6 +64,7 @@ inline int dict_lasso(dcp_handle* h, const T* Y, const real_t<T>* M, int mask_nd
     const int base = lasso_method & ~DCP_LASSO_POSITIVE;
     const bool positive = (lasso_method & DCP_LASSO_POSITIVE) != 0;
     LassoExtra extra;
+    extra.no_final_sync = true;            // the statistics product follows on the same stream
     if (base == DCP_LASSO_PARALLEL_CD) {   // the RNG stream of lasso.py:463,481 (dcp_dict_set_pcd_order)
         if (!h->pcd_order || h->pcd_K != K || h->pcd_rows < lasso_iter)
             return fail(h, DCP_ERR_INVALID, "parallel_cd inside the dictionary step: call "

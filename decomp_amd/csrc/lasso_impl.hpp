@@ -720,6 +720,9 @@ struct LassoExtra {
     const int* order = nullptr;   // parallel_cd: device int32 [order_rows, K] shuffle table
     int64_t order_rows = 0;
     double rho = 1.0;             // admm
+    // the caller enqueues more work on the same stream right behind the solve (the dictionary step's x^H [y | x]
+    // product): skip the stream synchronisation at the end -- *it_out is known on the host without it
+    bool no_final_sync = false;
 };
 
 // solve_fastpath (lasso.py:97-189).  Y [N,F], A [K,F], X [N,K] (in: initial estimate, out:
@@ -1143,7 +1146,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
     hipLaunchKernelGGL((col_scale_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st,
                        (const T*)result, (const R*)w.s, (long)N, (long)K, 0, X);
     DCP_LAUNCH_OK(h, hipGetLastError());
-    DCP_HIP_OK(h, hipStreamSynchronize(st));
+    if (!extra.no_final_sync) DCP_HIP_OK(h, hipStreamSynchronize(st));
     *it_out = it;
     return DCP_OK;
 }
