@@ -228,6 +228,44 @@ def dict_step_parity(torch, lib, h, step_name, Y, D, alpha=0.1, lasso_iter=10, l
             'pass': bool(lit.value == it2 and ex <= tol and eD <= tol)}
 
 
+def dict_step_cd_parity(torch, lib, h, Y, D, alpha=0.1, lasso_iter=10, lasso_tol=1e-5, n_rows=16):
+    """The same gate for the reference's DEFAULT inner solver (lasso_method='cd').  The reference's sweep
+    recomputes x.A for every coordinate (lasso.py:539-551: 1.8e14 flop for this minibatch), so the oracle runs
+    stage-wise: its as-written coordinate descent on `n_rows` rows spread over the minibatch pins the codes
+    (rows are independent given D; from x = 1 the stop test at sweep 0 cannot fire), and A, B + the sequential
+    atom sweep of the oracle, fed with the HIP path's codes, pin the D side."""
+    import numpy as np
+    from decomp_amd import _arrays, _hip
+    from oracle import dictionary_learning as odl, lasso as olasso
+    MB, F = Y.shape
+    K = D.shape[0]
+    x = torch.ones((MB, K), device=Y.device, dtype=D.dtype)
+    A = torch.zeros((K, K), device=Y.device, dtype=D.dtype)
+    B = torch.zeros((K, F), device=Y.device, dtype=D.dtype)
+    Dn = torch.empty_like(D)
+    md, lit = ctypes.c_double(0), ctypes.c_int(0)
+    _hip.check(h, lib.dcp_dict_step_f32(h, _arrays.ptr(Y), _arrays.ptr(x), _arrays.ptr(D), _arrays.ptr(Dn),
+                                        _arrays.ptr(A), _arrays.ptr(B), MB, F, K, (1.0 - MB) / 1.0, alpha,
+                                        _hip.LASSO_CD, lasso_iter, lasso_tol, ctypes.byref(md), ctypes.byref(lit)),
+               'dcp_dict_step_f32 (cd parity)')
+    gx, gD = x.cpu().numpy(), Dn.cpu().numpy()
+    y, d = Y.cpu().numpy(), D.cpu().numpy()
+    sel = np.arange(0, MB, max(1, MB // n_rows))
+    t0 = time.perf_counter()
+    it2, xs = olasso.solve_fastpath(y[sel], d, alpha, x=np.ones((len(sel), K), y.dtype), tol=lasso_tol,
+                                    maxiter=lasso_iter, method='cd')
+    cpu_s = time.perf_counter() - t0
+    beta = (1.0 - MB) / 1.0
+    oD = odl.atom_sweep(d, beta * np.zeros((K, K), y.dtype) + gx.T @ gx, beta * np.zeros((K, F), y.dtype) + gx.T @ y)
+    ex = float(np.max(np.abs(gx[sel] - xs))) / float(np.max(np.abs(xs)))
+    eD = float(np.max(np.abs(gD - oD))) / float(np.max(np.abs(oD)))
+    tol = 2.0e-4
+    return {'metric': 'one minibatch step, lasso_method=cd: codes of %d rows vs the oracle\'s as-written sweep; '
+                      'D_new vs the oracle\'s A, B + atom sweep on the HIP codes; max|diff| / max|oracle|' % len(sel),
+            'lasso_it_hip': lit.value, 'lasso_it_oracle': int(it2), 'x_rel_err': ex, 'D_rel_err': eD,
+            'tolerance': tol, 'oracle_s': cpu_s, 'pass': bool(lit.value == it2 and ex <= tol and eD <= tol)}
+
+
 def secondary_configs(torch, device, with_oracle=False):
     """The other BASELINE configs at their one-GPU shapes, measured live in a few seconds each (they
     are parity-test cases, not the headline; reported so that their numbers in DESIGN.md have a
@@ -270,6 +308,7 @@ def secondary_configs(torch, device, with_oracle=False):
     lib, h = _arrays.lib_handle(D)
     md, lit = ctypes.c_double(0), ctypes.c_int(0)
     dl_parity = dict_step_parity(torch, lib, h, 'dcp_dict_step_f32', Y, D) if with_oracle else None
+    cd_parity = dict_step_cd_parity(torch, lib, h, Y, D) if with_oracle else None
     state = {'D': D, 'Dn': D_new, 'count': 0}
 
     def dl_step(method=_hip.LASSO_ISTA):
@@ -298,6 +337,8 @@ def secondary_configs(torch, device, with_oracle=False):
     # codes carried over from the previous visit of the minibatch as in the reference's epochs
     out['dictionary_step_cd_ms'] = {'workload': "configs[2] minibatch 8192x4096 k=512 cd x10 fp32",
                                     'value': round(ms_of(lambda: dl_step(_hip.LASSO_CD), 6), 4)}
+    if cd_parity is not None:
+        out['dictionary_step_cd_ms']['parity'] = cd_parity
     del Y, x, A, B, D, D_new, Dt, xt
 
     # configs[3]: masked NMF MU, one GPU's shard 16384 x 4096, k = 256, 20 % missing, fp32
@@ -612,7 +653,7 @@ def main():
         print(json.dumps(out))
         if 'parity' in out and not out['parity']['pass']:
             raise SystemExit('parity gate FAILED: %r' % (out['parity'],))
-        for key in ('dictionary_step_ms', 'complex_dictionary_step_ms'):
+        for key in ('dictionary_step_ms', 'dictionary_step_cd_ms', 'complex_dictionary_step_ms'):
             par = (out.get('secondary') or {}).get(key, {})
             par = par.get('parity') if isinstance(par, dict) else None
             if par is not None and not par['pass']:
