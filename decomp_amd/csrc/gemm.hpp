@@ -17,7 +17,7 @@ namespace dcp {
 //   NT: C[M,N] = A[M,K] . B[N,K]^T(H)      NN: C[M,N] = A[M,K] . B[K,N]
 //   TN: C[M,N] = A[K,M]^T(H) . B[K,N]
 enum GemmForm { FORM_NT = 0, FORM_NN = 1, FORM_TN = 2 };
-enum TileSel { TILE_AUTO = 0, TILE_LARGE = 1, TILE_SMALL = 2, TILE_HUGE = 3, TILE_SMALL_DEEP = 4 };
+enum TileSel { TILE_AUTO = 0, TILE_LARGE = 1, TILE_SMALL = 2, TILE_HUGE = 3, TILE_SMALL_DEEP = 4, TILE_MID = 5 };
 
 template <class T>
 struct GemmArgs {
@@ -190,6 +190,7 @@ inline int pick_tier(int M, int N, int K, int tile_sel, bool will_split, bool re
     if (tile_sel == TILE_SMALL) return TIER_SMALL;
     if (tile_sel == TILE_SMALL_DEEP) return TIER_SMALL_DEEP;
     if (tile_sel == TILE_LARGE) return TIER_LARGE;
+    if (tile_sel == TILE_MID) return (FORM != FORM_TN && M >= 128 && N >= 128) ? TIER_MID : TIER_SMALL;
     if (tile_sel == TILE_HUGE) return FORM == FORM_TN ? TIER_LARGE : TIER_HUGE;
     // <= 64 output rows or columns (<= 64 atoms): a 128-wide tile would idle half of every MFMA and run
     // bounds-checked (Y.D^T 65536 x 64 x 4096: 0.60 ms on 128x128, 0.34 ms on 64x64; x^T Y 64 x 4160 x 65536: 1.07 -> 0.39 ms)
