@@ -121,3 +121,35 @@ def test_lasso_cd_many_atoms(K):
     assert it == ito == 2
     assert np.max(np.abs(x - xo)) <= 1e-9 * max(1.0, np.max(np.abs(xo)))
     assert np.count_nonzero(x) > 0
+
+
+def test_stream_switch_orders_the_workspace_arena():
+    """dcp_set_stream only records the new stream; the workspace arena shared by all calls of a handle is
+    ordered lazily by the next arena-using call (ws_reserve -> ws_order_streams).  Interleave solves on two
+    torch streams WITHOUT host synchronisation in between (each call returns after its own stream has the
+    result; the next call on the other stream immediately reuses the arena): every result must equal the one
+    computed alone."""
+    import torch
+    import decomp_amd
+    rng = np.random.RandomState(4)
+    probs = []
+    for N, F, K in ((700, 260, 24), (1500, 512, 64), (300, 1000, 16)):
+        xt = np.maximum(rng.randn(N, K), 0)
+        Dt = np.maximum(rng.randn(K, F), 0)
+        y = torch.from_numpy((xt @ Dt + 0.1 * np.abs(rng.randn(N, F))).astype(np.float32)).cuda()
+        D0 = torch.from_numpy(np.maximum(Dt + 0.3 * rng.randn(K, F), 0.1).astype(np.float32)).cuda()
+        probs.append((y, D0))
+    alone = [decomp_amd.nmf.solve(y, D0, tol=0.0, maxiter=6) for y, D0 in probs]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(3):
+        for i, (y, D0) in enumerate(probs):
+            st = s1 if (i + rep) % 2 == 0 else s2
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append((i, decomp_amd.nmf.solve(y, D0, tol=0.0, maxiter=6)))
+    torch.cuda.synchronize()
+    for i, (it, D, x) in outs:
+        assert it == alone[i][0]
+        assert torch.equal(D, alone[i][1]) and torch.equal(x, alone[i][2]), i
