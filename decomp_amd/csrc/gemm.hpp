@@ -237,6 +237,9 @@ inline int f64_tier(int M, int N, int tile_sel, int K = 1 << 30) {
     // (TILE_SMALL_DEEP -- the atom sweep's 64-row block products -- is a float32 tile choice; in double precision
     //  those products take the 64 x 128 tile here: the generic core needed 113 us for the 64 x 4096 x 512 one)
     if (tile_sel == TILE_SMALL) return F64_GENERIC;
+    // the caller split a deep reduction over a small square output itself (Gram matrix D D^T, 256 x 256 x 4096 in 16
+    // splits): 64 x 64 tiles give 256 workgroups where 128 x 128 tiles give 64 (37 -> 13 us)
+    if (tile_sel == TILE_SMALL_DEEP && M > 64 && N > 64 && M <= 1024 && N <= 1024) return F64_SQ64;
     if (M > 64 && N > 64) {
         // few 128 x 128 tiles (the D-side products of an MU step: 256 x 4096 -> 64 tiles on 256 CUs): 64 x 64 tiles
         // put four times as many workgroups on the chip; these products are latency bound

@@ -215,6 +215,7 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
             ProfScope ps(h, DCP_PROF_GRAM);
             GemmArgs<T> g;
             g.A = D; g.lda = F; g.B = D; g.ldb = F; g.M = K; g.N = K; g.K = F;
+            if (!std::is_same<T, float>::value) g.tile = TILE_SMALL_DEEP;   // float64: 64 x 64 tiles (see f64_tier)
             plan_splits<FORM_NT>(g, 512, kMaxSplits, 16);   // tiny output: 256-deep splits (measured best)
             DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, g, EpiSlab<T>{w.slabs, K, (long)K * K})));
             hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * K)), dim3(256), 0,
