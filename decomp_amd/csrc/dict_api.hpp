@@ -89,13 +89,13 @@ inline int dict_lasso(dcp_handle* h, const T* Y, const real_t<T>* M, int mask_nd
 template <class T>
 inline int dict_stats_core(dcp_handle* h, const T* Y, T* X, const T* D, int64_t Nb, int64_t F, int64_t K,
                            double alpha, int lasso_method, int lasso_iter, double lasso_tol, T* stats,
-                           int* lasso_it, LassoWs<T>& lw, DictWs<T>& dw) {
+                           int* lasso_it, LassoWs<T>& lw, DictWs<T>& dw, bool keep_slabs = false) {
     typedef real_t<T> R;
     int it = 0;
     DCP_TRY(dict_lasso<T>(h, Y, (const R*)nullptr, 0, D, X, Nb, F, K, alpha, lasso_tol, lasso_iter,
                           lasso_method, &it, lw));
     if (lasso_it) *lasso_it = it;
-    return dict_local_stats<T>(h, Y, X, Nb, F, K, stats, dw);
+    return dict_local_stats<T>(h, Y, X, Nb, F, K, stats, dw, keep_slabs);
 }
 
 template <class T>
@@ -176,9 +176,10 @@ inline int dict_step_api(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, T
     DCP_TRY(dict_carve_extra<T>(h, dw, Nb, F, K));
     T* stats = ws_alloc<T>(h, (size_t)K * (F + K));
     if (!stats) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
+    // one GPU: the statistics stay as ordered split-K partials and are summed by the A / B accumulation itself
     DCP_TRY(dict_stats_core<T>(h, Y, X, D, Nb, F, K, alpha, lasso_method, lasso_iter, lasso_tol, stats,
-                               lasso_it, lw, dw));
-    DCP_TRY(dict_update<T>(h, stats, (R)beta, A, B, D, Dnew, F, K, dw.scal, dw));
+                               lasso_it, lw, dw, /*keep_slabs=*/true));
+    DCP_TRY(dict_update<T>(h, dw.slabs, (R)beta, A, B, D, Dnew, F, K, dw.scal, dw, dw.stat_nslabs));
     void* hostv = nullptr;
     DCP_TRY(host_scratch(h, 64, &hostv));
     DCP_HIP_OK(h, hipMemcpyAsync(hostv, dw.scal, sizeof(R), hipMemcpyDeviceToHost, h->stream));

@@ -41,6 +41,31 @@ __global__ void __launch_bounds__(256) dict_accumulate_kernel(const T* __restric
     }
 }
 
+// The same with the statistics still in S ordered split-K partials (one GPU: nothing has to be all-reduced, so the
+// slab sum and the accumulation are one pass; same left-to-right order as reduce_slabs_kernel, hence the same bits).
+template <class T>
+__global__ void __launch_bounds__(256) dict_accumulate_slabs_kernel(const T* __restrict__ slabs, long stride, int S,
+                                                                    long K, long F, real_t<T> beta,
+                                                                    T* __restrict__ A, T* __restrict__ B) {
+    const long W = F + K;
+    const long n = K * W;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        T v = slabs[i];
+        int s = 1;
+        for (; s + 7 < S; s += 8) {
+            T u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = slabs[(long)(s + q) * stride + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v = add(v, u[q]);
+        }
+        for (; s < S; ++s) v = add(v, slabs[(long)s * stride + i]);
+        const long r = i / W, c = i - r * W;
+        if (c < F) B[r * F + c] = add(scale(B[r * F + c], beta), v);
+        else A[r * K + (c - F)] = add(scale(A[r * K + (c - F)], beta), v);
+    }
+}
+
 // out[i, :] = in[index[i], :]   (MinibatchData.shuffle / .array: utils/data.py:147-156)
 template <class T>
 __global__ void __launch_bounds__(256) gather_rows_kernel(const T* __restrict__ in, const long long* __restrict__ index,
@@ -151,6 +176,7 @@ struct DictWs {
     size_t slab_count = 0;
     R* partial = nullptr;   // max|dD| partials
     R* scal = nullptr;
+    int stat_nslabs = 0;    // set by dict_local_stats
     AtomWs<T> atom;         // the blocked atom sweep's buffers (atom_sweep.hpp)
     // float32 with K or F off the 64-grid: zero-padded copies [Kp,Kp], [Kp,Fp], [Kp,Fp] for the fused sweep
     T* padA = nullptr;
@@ -184,9 +210,11 @@ inline size_t dict_slab_elems(int64_t Nb, int64_t F, int64_t K) {
 }
 
 // stats[K, F+K] = X^H [Y | X] for this rank's rows of the minibatch
+// keep_slabs: leave the ordered split-K partials in w.slabs (w.stat_nslabs of them, K (F + K) apart) for
+// dict_update to sum while it accumulates; `stats` is then not written.
 template <class T>
 inline int dict_local_stats(dcp_handle* h, const T* Y, const T* X, int64_t Nb, int64_t F, int64_t K,
-                            T* stats, DictWs<T>& w) {
+                            T* stats, DictWs<T>& w, bool keep_slabs = false) {
     GemmArgs<T> a;
     a.A = X; a.lda = K; a.B = Y; a.ldb = F; a.B2 = X; a.ldb2 = K; a.n_b1 = (int)F;
     a.M = (int)K; a.N = (int)(F + K); a.K = (int)Nb;
@@ -195,6 +223,8 @@ inline int dict_local_stats(dcp_handle* h, const T* Y, const T* X, int64_t Nb, i
     const long W = F + K;
     if ((size_t)a.ksplits * K * W > w.slab_count) return fail(h, DCP_ERR_INTERNAL, "dict slab plan");
     DCP_LAUNCH_OK(h, (gemm<FORM_TN>(h->stream, a, EpiSlab<T>{w.slabs, W, (long)K * W})));
+    w.stat_nslabs = a.ksplits;
+    if (keep_slabs) return DCP_OK;
     hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * W)), dim3(256), 0, h->stream,
                        w.slabs, (long)K * W, a.ksplits, (long)K * W, stats);
     DCP_LAUNCH_OK(h, hipGetLastError());
@@ -204,11 +234,15 @@ inline int dict_local_stats(dcp_handle* h, const T* Y, const T* X, int64_t Nb, i
 // A,B accumulation + atom sweep + max|D - D_new| (device scalar)
 template <class T>
 inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B, const T* D, T* Dnew,
-                       int64_t F, int64_t K, real_t<T>* maxdiff_dev, DictWs<T>& w) {
+                       int64_t F, int64_t K, real_t<T>* maxdiff_dev, DictWs<T>& w, int stats_nslabs = 0) {
     typedef real_t<T> R;
     hipStream_t st = h->stream;
-    hipLaunchKernelGGL((dict_accumulate_kernel<T>), dim3(grid_for((long)K * (F + K))), dim3(256), 0, st,
-                       stats, (long)K, (long)F, beta, A, B);
+    if (stats_nslabs > 0)   // `stats` = ordered split-K partials (one GPU): sum and accumulate in one pass
+        hipLaunchKernelGGL((dict_accumulate_slabs_kernel<T>), dim3(grid_for((long)K * (F + K))), dim3(256), 0, st,
+                           stats, (long)K * (F + K), stats_nslabs, (long)K, (long)F, beta, A, B);
+    else
+        hipLaunchKernelGGL((dict_accumulate_kernel<T>), dim3(grid_for((long)K * (F + K))), dim3(256), 0, st,
+                           stats, (long)K, (long)F, beta, A, B);
     DCP_LAUNCH_OK(h, hipGetLastError());
     DCP_HIP_OK(h, hipMemcpyAsync(Dnew, D, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice, st));
     // blocked atom sweep (float32 with K, F multiples of 64: the fused three-launch path)
