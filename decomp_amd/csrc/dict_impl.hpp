@@ -269,7 +269,7 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
         }
     }
     if (!fused) DCP_TRY(atom_sweep<T>(h, A, B, Dnew, F, K, w.atom));
-    const int mb = grid_for((long)K * F, 256);
+    const int mb = grid_for((long)K * F, 512);   // (w.partial holds >= 514 entries)
     hipLaunchKernelGGL((maxabsdiff_partial_kernel<T>), dim3(mb), dim3(256), 0, st, D, (const T*)Dnew,
                        (long)K * F, w.partial);
     DCP_LAUNCH_OK(h, hipGetLastError());
