@@ -339,7 +339,33 @@ def secondary_configs(torch, device, with_oracle=False):
                                     'value': round(ms_of(lambda: dl_step(_hip.LASSO_CD), 6), 4)}
     if cd_parity is not None:
         out['dictionary_step_cd_ms']['parity'] = cd_parity
-    del Y, x, A, B, D, D_new, Dt, xt
+    del Y, x, A, B, D_new, xt
+
+    # configs[2] END TO END through the public API: decomp_amd.dictionary_learning.solve on device
+    # tensors, Y 65536 x 4096, k = 512, minibatch 8192, ista x 10, maxiter = 4 -> 3 epochs = 24 minibatch steps,
+    # wall clock / 24 -- shuffle, per-step row gathers, stop test and the final copy-out included.
+    import decomp_amd
+    NT = 65536
+    xt = 30.0 * torch.randn((NT, K), generator=g, device=device) * (torch.rand((NT, K), generator=g, device=device) < 0.05)
+    Yfull = xt @ Dt
+    del xt
+    for r0 in range(0, NT, 8192):
+        Yfull[r0:r0 + 8192] += 0.1 * torch.randn((8192, F), generator=g, device=device)
+    kw = dict(tol=0.0, minibatch=MB, lasso_method='ista', lasso_iter=10, lasso_tol=1e-5, random_seed=0)
+    decomp_amd.dictionary_learning.solve(Yfull, D, 0.1, maxiter=2, **kw)          # warm-up: one epoch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    it_e2e, D_e2e, x_e2e = decomp_amd.dictionary_learning.solve(Yfull, D, 0.1, maxiter=4, **kw)
+    torch.cuda.synchronize()
+    e2e_ms = 1e3 * (time.perf_counter() - t0) / (3 * (NT // MB))
+    out['dictionary_learning_solve_ms_per_step'] = {
+        'workload': 'configs[2] END TO END: decomp_amd.dictionary_learning.solve(Y 65536x4096 fp32 on the device, k=512, '
+                    'minibatch=8192, lasso_method=ista, lasso_iter=10, maxiter=4): wall clock of the call / 24 steps',
+        'value': round(e2e_ms, 4), 'it': int(it_e2e),
+        'finite': bool(torch.isfinite(D_e2e).all().item()) and bool(torch.isfinite(x_e2e).all().item()),
+        'code_density': float((x_e2e != 0).float().mean().item()),
+        'vs_step_kernel_figure': round(e2e_ms / out['dictionary_step_ms']['value'], 4)}
+    del Yfull, D_e2e, x_e2e, D, Dt
 
     # configs[3]: masked NMF MU, one GPU's shard 16384 x 4096, k = 256, 20 % missing, fp32
     N, F, K = 16384, 4096, 256
@@ -382,11 +408,25 @@ def secondary_configs(torch, device, with_oracle=False):
         _hip.check(h, lib.dcp_nmf_mu_f32(h, _arrays.ptr(Ys), None, _arrays.ptr(xs), _arrays.ptr(Ds), Ns, F, K,
                                          _hip.LIK_L2, ctypes.c_float(0.0), n + 1, ctypes.byref(it), None, None),
                    'nmf_mu shard')
-    ms = ms_of(shard, 3) / 10
+    ms_plain = ms_of(shard, 3) / 10
+    # the loop a rank of an 8-GPU run executes: dcp_nmf_mu_sharded_f32 with the handle's RCCL communicator
+    # (here a 1-rank communicator: the all-reduce call is issued every step, its wire time is not in it)
+    from decomp_amd import sharded as _sh
+    ms = None
+    if _sh.attach_communicator(Ds):
+        def shard_rank(n=10):
+            _sh.mu_solve_in_library(Ys, None, xs, Ds, _hip.LIK_L2, 0.0, n + 1)
+        ms = ms_of(shard_rank, 3) / 10
+        _sh.detach_communicator(Ds)
     Ws = 4.0 * Ns * K * F + 4.0 * Ns * K * K + 4.0 * K * K * F
-    out['shard_8192_rows_ms_per_iter'] = {'workload': 'one 8192-row shard of configs[1] on one GPU, no collective',
-                                          'value': round(ms, 4), 'tflops': round(Ws / ms / 1e9, 1),
-                                          'compute_side_speedup_at_8_gpus': None}
+    shipped = ms if ms is not None else ms_plain
+    out['shard_8192_rows_ms_per_iter'] = {
+        'workload': 'one 8192-row shard of configs[1] on one GPU through dcp_nmf_mu_sharded_f32 (the loop a rank of '
+                    'an 8-GPU run executes; 1-rank RCCL communicator, so the exchange is issued but costs no wire '
+                    'time)' if ms is not None else 'one 8192-row shard of configs[1], dcp_nmf_mu_f32 (RCCL unavailable)',
+        'value': round(shipped, 4), 'tflops': round(Ws / shipped / 1e9, 1),
+        'without_exchange_call_ms': round(ms_plain, 4),
+        'compute_side_speedup_at_8_gpus': None}
     del Y, Ys, xs, Ds, x
     # the usual NMF ranks are far below the headline's 256 atoms: same Y shape as configs[1] per 16384 rows, k = 32
     # (narrow 128x32 / 32x128 tiles; the step is bound by reading Y twice)
@@ -455,6 +495,19 @@ def main():
                          'shard of a larger run without the collective')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` as ONE command: this parent has made no GPU call (torch is not even
+        # imported yet); it starts the N ranks (one process per GPU) and exits with their return code.
+        # Rank 0's JSON line goes to the inherited stdout.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import torch
     import torch.distributed as dist
     from decomp_amd import _arrays, _hip, sharded
@@ -462,10 +515,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
-        args.gpus = world
+    args.gpus = world
     # one rank per GPU; DCP_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the
     # launch path on a 1-GPU box -- never a measurement)
     backend = os.environ.get('DCP_DIST_BACKEND', 'nccl')
@@ -490,6 +540,15 @@ def main():
     torch.cuda.synchronize()
 
     lib, h = _arrays.lib_handle(D)
+    # Multi-GPU (and --force-sharded on one GPU): the loop a rank runs is dcp_nmf_mu_sharded_f32 -- the step
+    # with the RCCL all-reduce of the statistics enqueued on the solver's own stream inside the library.  Only
+    # when RCCL cannot serve the process group (DCP_DIST_BACKEND=gloo rehearsals: several ranks on one GPU)
+    # does the Python loop over torch.distributed run instead; the JSON line says which (`config.loop`).
+    sharded_run = world > 1 or args.force_sharded
+    in_library = sharded_run and sharded.attach_communicator(D)
+    loop_name = ('single-GPU dcp_nmf_mu_f32' if not sharded_run else
+                 'in-library dcp_nmf_mu_sharded_f32 (ncclAllReduce on the solver stream)' if in_library else
+                 'python sharded.mu_loop over torch.distributed (%s)' % backend)
 
     def barrier():
         torch.cuda.synchronize()
@@ -499,13 +558,17 @@ def main():
 
     def run(n_steps):
         """n_steps MU iterations (tol = 0: the stop test is evaluated, never met)."""
-        if world == 1 and not args.force_sharded:
+        if not sharded_run:
             it = ctypes.c_int(0)
             rc = lib.dcp_nmf_mu_f32(h, _arrays.ptr(Y), None, _arrays.ptr(x), _arrays.ptr(D),
                                     rows, N_FEAT, N_ATOMS, _hip.LIK_L2, ctypes.c_float(0.0),
                                     n_steps + 1, ctypes.byref(it), None, None)
             _hip.check(h, rc, 'dcp_nmf_mu_f32')
             assert it.value == n_steps + 1
+            return D
+        if in_library:
+            it = sharded.mu_solve_in_library(Y, None, state['x'], D, _hip.LIK_L2, 0.0, n_steps + 1)
+            assert it == n_steps + 1
             return D
         backend = sharded.HipStepBackend(Y, None, state['x'], D, _hip.LIK_L2)
         it, Dout = sharded.mu_loop(backend, D, 0.0, n_steps + 1, world_size=world,
@@ -561,41 +624,50 @@ def main():
 
     # Multi-GPU (or --force-sharded): where one step's time goes on THIS rank -- local statistics (x update +
     # x^T [Y | x]), the exchange (ONE all-reduce of [K, F+K]; its time includes waiting for the slowest rank)
-    # and the replicated D update -- from torch events over a few untimed steps; max over ranks reported.
+    # and the replicated D update; max over ranks reported.  In-library loop: the hipEvent brackets of the
+    # breakdown pass above (the all-reduce has its own label); Python loop: torch events around its three calls.
     phase_ms = None
-    if world > 1 or args.force_sharded:
-        be = sharded.HipStepBackend(Y, None, state['x'], D, _hip.LIK_L2)
-        Dn2 = torch.empty_like(D)
-        Dc2 = D
-        acc = [0.0, 0.0, 0.0]
-        n_ph = 8
-        for it in range(n_ph + 2):
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            ev[0].record()
-            st_ = be.local_stats(Dc2)
-            ev[1].record()
-            if world > 1:
-                dist.all_reduce(st_, op=dist.ReduceOp.SUM)
-            ev[2].record()
-            be.update(st_, Dc2, Dn2, it & 1)
-            ev[3].record()
-            torch.cuda.synchronize()
-            if it >= 2:
-                for j in range(3):
-                    acc[j] += ev[j].elapsed_time(ev[j + 1])
-            Dc2, Dn2 = Dn2, Dc2
-        state['x'] = be.x
-        t3 = torch.tensor([a_ / n_ph for a_ in acc], dtype=torch.float64, device=device)
+    if sharded_run:
+        if in_library:
+            def grp(*names):
+                return sum(breakdown[n]['ms_avg'] for n in names if n in breakdown)
+            acc = [grp('gram', 'x_neg', 'x_update', 'forward', 'stats', 'stats_sum'), grp('exchange'),
+                   grp('d_update', 'd_norm')]
+            how = 'hipEvent brackets inside dcp_nmf_mu_sharded_f32 over %d untimed steps' % min(10, args.steps)
+        else:
+            be = sharded.HipStepBackend(Y, None, state['x'], D, _hip.LIK_L2)
+            Dn2 = torch.empty_like(D)
+            Dc2 = D
+            acc = [0.0, 0.0, 0.0]
+            n_ph = 8
+            for it in range(n_ph + 2):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                ev[0].record()
+                st_ = be.local_stats(Dc2)
+                ev[1].record()
+                if world > 1:
+                    dist.all_reduce(st_, op=dist.ReduceOp.SUM)
+                ev[2].record()
+                be.update(st_, Dc2, Dn2, it & 1)
+                ev[3].record()
+                torch.cuda.synchronize()
+                if it >= 2:
+                    for j in range(3):
+                        acc[j] += ev[j].elapsed_time(ev[j + 1])
+                Dc2, Dn2 = Dn2, Dc2
+            state['x'] = be.x
+            acc = [a_ / n_ph for a_ in acc]
+            how = 'torch events around the three calls of the Python loop, synchronised after every step'
+        t3 = torch.tensor(acc, dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(t3, op=dist.ReduceOp.MAX)
         K_, W_ = N_ATOMS, N_FEAT + N_ATOMS
         phase_ms = {'local_stats': round(float(t3[0]), 4), 'exchange_all_reduce': round(float(t3[1]), 4),
                     'replicated_update': round(float(t3[2]), 4),
                     'exchange_bytes_per_step': 4 * K_ * W_,
-                    'note': 'per-phase GPU time of one step, max over ranks, synchronised after every step '
-                            '(diagnostic; the timed region above runs without these synchronisations). The '
-                            'all-reduce is fully exposed between the two compute phases: each depends on the '
-                            'other (DESIGN.md section 5).'}
+                    'note': 'per-phase GPU time of one step, max over ranks (%s; diagnostic, the timed region '
+                            'runs without brackets). The all-reduce is fully exposed between the two compute '
+                            'phases: each depends on the other (DESIGN.md section 5).' % how}
 
     finite = bool(torch.isfinite(Dcur).all().item()) and bool(torch.isfinite(state['x']).all().item())
 
@@ -609,7 +681,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('nmf_mu l2 no-mask Y=65536x4096 k=256 fp32 (BASELINE configs[1])'
                                     if not args.rows else 'ANALYSIS ONLY: one shard of %d rows' % rows),
-                       'rows_per_gpu': rows, 'parallelism': 'rows sharded x%d, 1 all-reduce/step' % world},
+                       'rows_per_gpu': rows, 'parallelism': 'rows sharded x%d, 1 all-reduce/step' % world,
+                       'loop': loop_name},
             'algorithmic_tflops': W / (elapsed / args.steps) / 1e12,
             'mfma_roofline_frac_whole_step': W / (elapsed / args.steps) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
             'finite': finite,
@@ -619,7 +692,10 @@ def main():
             out['phase_ms'] = phase_ms
         # dominant kernel: the fused Y.D^T GEMM + MU quotient (2.N.K.F flop per launch)
         dom = prof.get('x_update')
-        traffic, traffic_src = pmc_traffic('0, 0, false, EpiMuNum<float>')
+        if world == 1 and not args.rows:
+            traffic, traffic_src = pmc_traffic('0, 0, false, EpiMuNum<float>')
+        else:   # the committed PMC pass is the N = 1 run of the full shape; a shard's launch is another kernel
+            traffic, traffic_src = None, 'not collected for this configuration (PMC pass exists for N=1 only)'
         if dom:
             flops = 2.0 * rows * N_ATOMS * N_FEAT
             ach = flops / (dom['ms_avg'] * 1e-3) / 1e12

@@ -13,14 +13,17 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libdecomp_hip.so')
 
 OK = 0
 ERR_NAMES = {-1: 'DCP_ERR_INVALID', -2: 'DCP_ERR_HIP', -3: 'DCP_ERR_NOMEM',
-             -4: 'DCP_ERR_INTERNAL', -5: 'DCP_ERR_UNSUPPORTED', -6: 'DCP_ERR_REF_TYPEERROR'}
+             -4: 'DCP_ERR_INTERNAL', -5: 'DCP_ERR_UNSUPPORTED', -6: 'DCP_ERR_REF_TYPEERROR',
+             -7: 'DCP_ERR_COMM'}
 LIK_L2, LIK_KL = 0, 1
-PROF_NLABELS = 9
+PROF_NLABELS = 10
 PROF_XUPDATE, PROF_STATS = 2, 4
 LASSO_ISTA, LASSO_ACC_ISTA, LASSO_FISTA, LASSO_CD = 0, 1, 2, 3
 LASSO_PARALLEL_CD, LASSO_ADMM = 4, 5
 LASSO_POSITIVE = 0x100
 ERR_REF_TYPEERROR = -6
+ERR_COMM = -7
+COMM_ID_BYTES = 128
 
 _c_int, _c_i64, _c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
 _c_f32, _c_f64 = ctypes.c_float, ctypes.c_double
@@ -34,6 +37,16 @@ SIGNATURES = {
     'dcp_set_stream': (_c_int, [_c_vp, _c_vp]),
     'dcp_last_error_string': (ctypes.c_char_p, [_c_vp]),
     'dcp_build_info': (ctypes.c_char_p, []),
+    'dcp_comm_unique_id': (_c_int, [_c_vp, _c_i64]),
+    'dcp_comm_init': (_c_int, [_c_vp, _c_vp, _c_int, _c_int]),
+    'dcp_comm_destroy': (_c_int, [_c_vp]),
+    'dcp_comm_info': (_c_int, [_c_vp, _P(_c_int), _P(_c_int)]),
+    'dcp_comm_allreduce_sum_f32': (_c_int, [_c_vp, _c_vp, _c_i64]),
+    'dcp_comm_allreduce_sum_f64': (_c_int, [_c_vp, _c_vp, _c_i64]),
+    'dcp_nmf_mu_sharded_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
+                                        _c_int, _c_f32, _c_int, _P(_c_int), _P(_c_f32)]),
+    'dcp_nmf_mu_sharded_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
+                                        _c_int, _c_f64, _c_int, _P(_c_int), _P(_c_f64)]),
     'dcp_profile_enable': (_c_int, [_c_vp, _c_int]),
     'dcp_profile_reset': (_c_int, [_c_vp]),
     'dcp_profile_select': (_c_int, [_c_vp, ctypes.c_uint]),
@@ -67,18 +80,22 @@ SIGNATURES = {
     'dcp_dict_stats_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
     'dcp_dict_update_f32': (_c_int, [_c_vp, _c_vp, _c_f64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_step_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_dict_step_async_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
     'dcp_gather_rows_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_stats_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
     'dcp_dict_update_f64': (_c_int, [_c_vp, _c_vp, _c_f64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_step_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_dict_step_async_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
     'dcp_gather_rows_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_stats_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
     'dcp_dict_update_c64': (_c_int, [_c_vp, _c_vp, _c_f64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_step_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_dict_step_async_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
     'dcp_gather_rows_c64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_stats_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
     'dcp_dict_update_c128': (_c_int, [_c_vp, _c_vp, _c_f64, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_step_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
+    'dcp_dict_step_async_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _c_vp, _P(_c_int)]),
     'dcp_gather_rows_c128': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_mask_step_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),
     'dcp_dict_mask_step_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_f64, _P(_c_f64), _P(_c_int)]),

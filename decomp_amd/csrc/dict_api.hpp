@@ -153,39 +153,66 @@ inline int dict_update_api(dcp_handle* h, const T* stats, double beta, T* A, T* 
     return dict_update<T>(h, stats, (R)beta, A, B, D, Dnew, F, K, maxdiff_dev, dw);
 }
 
-// dictionary_learning.py:137-164 for one minibatch on one GPU.
+// dictionary_learning.py:137-164 for one minibatch on one GPU; max|D - D_new| lands in the DEVICE scalar
+// maxdiff_dev (caller memory, or the workspace scalar when null), nothing waits for the GPU.
 template <class T>
-inline int dict_step_api(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, T* A, T* B, int64_t Nb,
-                         int64_t F, int64_t K, double beta, double alpha, int lasso_method,
-                         int lasso_iter, double lasso_tol, double* maxdiff_host, int* lasso_it) {
+inline int dict_step_core(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, T* A, T* B, int64_t Nb,
+                          int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                          int lasso_iter, double lasso_tol, real_t<T>* maxdiff_dev, int* lasso_it,
+                          real_t<T>** scal_out) {
     typedef real_t<T> R;
     DCP_TRY(dict_check<T>(h, Y, X, D, Nb, F, K));
-    if (!Dnew || !A || !B || !maxdiff_host) return fail(h, DCP_ERR_INVALID, "null pointer");
+    if (!Dnew || !A || !B) return fail(h, DCP_ERR_INVALID, "null pointer");
     if (!dict_lasso_method_ok(lasso_method))
         return fail(h, DCP_ERR_INVALID, "bad lasso method");
     DCP_HIP_OK(h, hipSetDevice(h->device));
     WsPlan plan;
     lasso_plan<T>(plan, Nb, F, K, 0, lasso_method & ~DCP_LASSO_POSITIVE);
     dict_plan_extra<T>(plan, Nb, F, K);
-    plan.add<T>((size_t)K * (F + K));
     DCP_TRY(ws_reserve(h, plan.total));
     ws_reset(h);
     LassoWs<T> lw;
     DictWs<T> dw;
     DCP_TRY(lasso_carve<T>(h, lw, Nb, F, K, 0, lasso_method & ~DCP_LASSO_POSITIVE));
     DCP_TRY(dict_carve_extra<T>(h, dw, Nb, F, K));
-    T* stats = ws_alloc<T>(h, (size_t)K * (F + K));
-    if (!stats) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
-    // one GPU: the statistics stay as ordered split-K partials and are summed by the A / B accumulation itself
-    DCP_TRY(dict_stats_core<T>(h, Y, X, D, Nb, F, K, alpha, lasso_method, lasso_iter, lasso_tol, stats,
+    // one GPU: the statistics stay as ordered split-K partials (no [K, F+K] sum is formed: `stats` = null) and
+    // are summed by the A / B accumulation itself
+    DCP_TRY(dict_stats_core<T>(h, Y, X, D, Nb, F, K, alpha, lasso_method, lasso_iter, lasso_tol, (T*)nullptr,
                                lasso_it, lw, dw, /*keep_slabs=*/true));
-    DCP_TRY(dict_update<T>(h, dw.slabs, (R)beta, A, B, D, Dnew, F, K, dw.scal, dw, dw.stat_nslabs));
+    R* md = maxdiff_dev ? maxdiff_dev : dw.scal;
+    DCP_TRY(dict_update<T>(h, dw.slabs, (R)beta, A, B, D, Dnew, F, K, md, dw, dw.stat_nslabs));
+    if (scal_out) *scal_out = md;
+    return DCP_OK;
+}
+
+template <class T>
+inline int dict_step_api(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, T* A, T* B, int64_t Nb,
+                         int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                         int lasso_iter, double lasso_tol, double* maxdiff_host, int* lasso_it) {
+    typedef real_t<T> R;
+    if (!h) return DCP_ERR_INVALID;
+    if (!maxdiff_host) return fail(h, DCP_ERR_INVALID, "null pointer");
+    R* md = nullptr;
+    DCP_TRY(dict_step_core<T>(h, Y, X, D, Dnew, A, B, Nb, F, K, beta, alpha, lasso_method, lasso_iter, lasso_tol,
+                              (R*)nullptr, lasso_it, &md));
     void* hostv = nullptr;
     DCP_TRY(host_scratch(h, 64, &hostv));
-    DCP_HIP_OK(h, hipMemcpyAsync(hostv, dw.scal, sizeof(R), hipMemcpyDeviceToHost, h->stream));
+    DCP_HIP_OK(h, hipMemcpyAsync(hostv, md, sizeof(R), hipMemcpyDeviceToHost, h->stream));
     DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
     *maxdiff_host = (double)(*reinterpret_cast<R*>(hostv));
     return DCP_OK;
+}
+
+// The same step without the host read-back (dictionary_learning.py:161-162 is then evaluated by the caller one
+// step late, from the device scalar).
+template <class T>
+inline int dict_step_async_api(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, T* A, T* B, int64_t Nb,
+                               int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                               int lasso_iter, double lasso_tol, real_t<T>* maxdiff_dev, int* lasso_it) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!maxdiff_dev) return fail(h, DCP_ERR_INVALID, "null pointer");
+    return dict_step_core<T>(h, Y, X, D, Dnew, A, B, Nb, F, K, beta, alpha, lasso_method, lasso_iter, lasso_tol,
+                             maxdiff_dev, lasso_it, nullptr);
 }
 
 // dictionary_learning.py:192-225 for one minibatch with a mask (solve_cd_mask).

@@ -23,6 +23,13 @@ int dcp_dict_step_c128(dcp_handle* h, const void* Y, void* X, const void* D, voi
                                   lasso_method, lasso_iter, lasso_tol, maxdiff, lasso_it);
 }
 
+int dcp_dict_step_async_c128(dcp_handle* h, const void* Y, void* X, const void* D, void* D_new, void* A, void* B, int64_t Nb,
+                             int64_t F, int64_t K, double beta, double alpha, int lasso_method, int lasso_iter,
+                             double lasso_tol, double* maxdiff_dev, int* lasso_it) {
+    return dcp::dict_step_async_api<dcp::cx<double>>(h, reinterpret_cast<const dcp::cx<double>*>(Y), reinterpret_cast<dcp::cx<double>*>(X), reinterpret_cast<const dcp::cx<double>*>(D), reinterpret_cast<dcp::cx<double>*>(D_new), reinterpret_cast<dcp::cx<double>*>(A), reinterpret_cast<dcp::cx<double>*>(B), Nb, F, K, beta, alpha,
+                                        lasso_method, lasso_iter, lasso_tol, maxdiff_dev, lasso_it);
+}
+
 int dcp_gather_rows_c128(dcp_handle* h, const void* in, const int64_t* index, int64_t rows, int64_t cols,
                          void* out) {
     return dcp::gather_rows_api<dcp::c128>(h, reinterpret_cast<const dcp::c128*>(in), reinterpret_cast<const long long*>(index), rows, cols,

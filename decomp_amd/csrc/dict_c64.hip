@@ -23,6 +23,13 @@ int dcp_dict_step_c64(dcp_handle* h, const void* Y, void* X, const void* D, void
                                   lasso_method, lasso_iter, lasso_tol, maxdiff, lasso_it);
 }
 
+int dcp_dict_step_async_c64(dcp_handle* h, const void* Y, void* X, const void* D, void* D_new, void* A, void* B, int64_t Nb,
+                             int64_t F, int64_t K, double beta, double alpha, int lasso_method, int lasso_iter,
+                             double lasso_tol, float* maxdiff_dev, int* lasso_it) {
+    return dcp::dict_step_async_api<dcp::cx<float>>(h, reinterpret_cast<const dcp::cx<float>*>(Y), reinterpret_cast<dcp::cx<float>*>(X), reinterpret_cast<const dcp::cx<float>*>(D), reinterpret_cast<dcp::cx<float>*>(D_new), reinterpret_cast<dcp::cx<float>*>(A), reinterpret_cast<dcp::cx<float>*>(B), Nb, F, K, beta, alpha,
+                                        lasso_method, lasso_iter, lasso_tol, maxdiff_dev, lasso_it);
+}
+
 int dcp_gather_rows_c64(dcp_handle* h, const void* in, const int64_t* index, int64_t rows, int64_t cols,
                          void* out) {
     return dcp::gather_rows_api<dcp::c64>(h, reinterpret_cast<const dcp::c64*>(in), reinterpret_cast<const long long*>(index), rows, cols,

@@ -23,6 +23,13 @@ int dcp_dict_step_f32(dcp_handle* h, const float* Y, float* X, const float* D, f
                                   lasso_method, lasso_iter, lasso_tol, maxdiff, lasso_it);
 }
 
+int dcp_dict_step_async_f32(dcp_handle* h, const float* Y, float* X, const float* D, float* D_new, float* A, float* B, int64_t Nb,
+                             int64_t F, int64_t K, double beta, double alpha, int lasso_method, int lasso_iter,
+                             double lasso_tol, float* maxdiff_dev, int* lasso_it) {
+    return dcp::dict_step_async_api<float>(h, (Y), (X), (D), (D_new), (A), (B), Nb, F, K, beta, alpha,
+                                        lasso_method, lasso_iter, lasso_tol, maxdiff_dev, lasso_it);
+}
+
 int dcp_gather_rows_f32(dcp_handle* h, const float* in, const int64_t* index, int64_t rows, int64_t cols,
                          float* out) {
     return dcp::gather_rows_api<float>(h, (in), reinterpret_cast<const long long*>(index), rows, cols,

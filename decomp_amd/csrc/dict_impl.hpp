@@ -211,7 +211,7 @@ inline size_t dict_slab_elems(int64_t Nb, int64_t F, int64_t K) {
 
 // stats[K, F+K] = X^H [Y | X] for this rank's rows of the minibatch
 // keep_slabs: leave the ordered split-K partials in w.slabs (w.stat_nslabs of them, K (F + K) apart) for
-// dict_update to sum while it accumulates; `stats` is then not written.
+// dict_update to sum while it accumulates; `stats` is then neither read nor written (pass nullptr).
 template <class T>
 inline int dict_local_stats(dcp_handle* h, const T* Y, const T* X, int64_t Nb, int64_t F, int64_t K,
                             T* stats, DictWs<T>& w, bool keep_slabs = false) {
@@ -225,6 +225,7 @@ inline int dict_local_stats(dcp_handle* h, const T* Y, const T* X, int64_t Nb, i
     DCP_LAUNCH_OK(h, (gemm<FORM_TN>(h->stream, a, EpiSlab<T>{w.slabs, W, (long)K * W})));
     w.stat_nslabs = a.ksplits;
     if (keep_slabs) return DCP_OK;
+    if (!stats) return fail(h, DCP_ERR_INTERNAL, "dict_local_stats: stats is null");
     hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * W)), dim3(256), 0, h->stream,
                        w.slabs, (long)K * W, a.ksplits, (long)K * W, stats);
     DCP_LAUNCH_OK(h, hipGetLastError());

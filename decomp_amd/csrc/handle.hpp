@@ -36,6 +36,9 @@ struct dcp_handle {
     void* host_pinned = nullptr;
     size_t host_pinned_bytes = 0;
     std::string err;
+    // RCCL communicator of the sample-sharded solvers (comm.hip; ncclComm_t kept opaque here)
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
     // parallel_cd inside the dictionary step: the caller-supplied shuffle table (dcp_dict_set_pcd_order)
     const int* pcd_order = nullptr;
     int64_t pcd_rows = 0, pcd_K = 0;

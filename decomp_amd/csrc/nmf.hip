@@ -1,5 +1,6 @@
 // C ABI: NMF multiplicative update (see include/decomp_hip.h for the contract and the
 // reference lines each entry point replaces).
+#include "comm.hpp"
 #include "nmf_impl.hpp"
 
 using namespace dcp;
@@ -21,9 +22,11 @@ int check_nmf_args(dcp_handle* h, const T* Y, const T* X, const T* D, int64_t N,
 template <class T>
 int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N, int64_t F,
                  int64_t K, int lik, T tol, int maxiter, int* it_out, T* last_maxdiff,
-                 T* resid_trace) {
+                 T* resid_trace, bool sharded = false) {
     DCP_TRY(check_nmf_args(h, Y, X, D, N, F, K, lik));
     if (!it_out) return fail(h, DCP_ERR_INVALID, "it_out is null");
+    if (sharded && !comm_active(h))
+        return fail(h, DCP_ERR_COMM, "dcp_nmf_mu_sharded_* needs a communicator (dcp_comm_init)");
     DCP_HIP_OK(h, hipSetDevice(h->device));
     const bool masked = mask != nullptr;
     NmfShape<T> s{N, F, K, lik, masked};
@@ -107,6 +110,11 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     for (int it = 1; it < maxiter; ++it) {  // batch_mu.py:16
         const int slot = it & 1;
         DCP_TRY(nmf_stats<T>(h, Ypre, mask, Xc, Xn, Dc, s, stats, ws));
+        if (sharded) {   // the one exchange of the step: sums over rows become sums over ranks
+            ProfScope ps(h, DCP_PROF_EXCHANGE);
+            DCP_TRY(comm_allreduce_sum(h, stats, (size_t)K * W,
+                                       std::is_same<T, float>::value ? COMM_F32 : COMM_F64));
+        }
         DCP_TRY(nmf_update<T>(h, stats, Dc, Dn, F, K, lik, masked, maxdiff_dev + slot, wu,
                               maxdiff_dev + (slot ^ 1)));
         DCP_HIP_OK(h, hipMemcpyAsync(host_md + slot, maxdiff_dev + slot, sizeof(T),
@@ -501,6 +509,18 @@ int dcp_nmf_mu_f64(dcp_handle* h, const double* Y, const double* mask, double* X
                    int* it_out, double* last_maxdiff, double* resid_trace) {
     return nmf_mu_solve<double>(h, Y, mask, X, D, N, F, K, likelihood, tol, maxiter, it_out,
                                 last_maxdiff, resid_trace);
+}
+int dcp_nmf_mu_sharded_f32(dcp_handle* h, const float* Y, const float* mask, float* X, float* D, int64_t N,
+                           int64_t F, int64_t K, int likelihood, float tol, int maxiter, int* it_out,
+                           float* last_maxdiff) {
+    return nmf_mu_solve<float>(h, Y, mask, X, D, N, F, K, likelihood, tol, maxiter, it_out,
+                               last_maxdiff, nullptr, true);
+}
+int dcp_nmf_mu_sharded_f64(dcp_handle* h, const double* Y, const double* mask, double* X, double* D,
+                           int64_t N, int64_t F, int64_t K, int likelihood, double tol, int maxiter,
+                           int* it_out, double* last_maxdiff) {
+    return nmf_mu_solve<double>(h, Y, mask, X, D, N, F, K, likelihood, tol, maxiter, it_out,
+                                last_maxdiff, nullptr, true);
 }
 int dcp_nmf_mu_stats_f32(dcp_handle* h, const float* Y, const float* mask, const float* X,
                          float* X_out, const float* D, int64_t N, int64_t F, int64_t K,

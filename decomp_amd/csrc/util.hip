@@ -1,4 +1,5 @@
 // C ABI: handle lifetime, row normalisation, sign scan, and the GEMM test hook.
+#include "comm.hpp"
 #include "gemm.hpp"
 #include "handle.hpp"
 #include "kernels_small.hpp"
@@ -430,6 +431,7 @@ int dcp_create(dcp_handle** out, int device) {
 int dcp_destroy(dcp_handle* h) {
     if (!h) return DCP_OK;
     (void)hipSetDevice(h->device);
+    comm_release(h);
     if (h->arena) {
         (void)hipStreamSynchronize(h->stream);
         (void)hipFree(h->arena);
@@ -514,7 +516,7 @@ int dcp_profile_read(dcp_handle* h, int label, double* total_ms, int64_t* count)
 
 const char* dcp_profile_label_name(int label) {
     static const char* names[DCP_PROF_NLABELS] = {"gram",  "x_neg",     "x_update", "forward", "stats",
-                                                  "stats_sum", "d_update", "d_norm",  "misc"};
+                                                  "stats_sum", "d_update", "d_norm",  "misc", "exchange"};
     return (label >= 0 && label < DCP_PROF_NLABELS) ? names[label] : "?";
 }
 

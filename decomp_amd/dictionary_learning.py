@@ -9,11 +9,20 @@ minibatch composition is identical); each minibatch step -- LASSO inner solve, t
 A / B statistics, the sequential atom sweep and max|D - D_new| -- is one call into
 libdecomp_hip.so (``dcp_dict_step_*``, decomp_amd/csrc/dict_impl.hpp).
 
+In-core data (y, x on the device; the BASELINE configs) take ``solve_cd_indexed``: y is never
+permuted or copied -- the reference's cumulative shuffle (utils/data.py:152-156: a full gather of
+y and x per epoch) becomes an index, each step gathers only ITS minibatch rows into a reused
+staging block (the rows of step s+1 on a side stream while step s computes), the stop test
+``max|D - D_new| < tol`` (dictionary_learning.py:161-162) is read one step late so the host never
+idles the GPU, and a speculative step after a passed test is discarded.  Same minibatch
+composition, same arithmetic per step, same return values.
+
 ``mask`` selects the masked variant (solve_cd_mask, dictionary_learning.py:171-231): same
 structure with a per-channel [K, F, K] Gram statistic (``dcp_dict_mask_step_*``; a parity
 path, single GPU, memory K*F*K elements as in the reference).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -74,6 +83,19 @@ def solve(y, D, alpha, x=None, tol=1.0e-3,
             t = t.to(rdt)
         return MinibatchData(t.contiguous(), minibatch)
 
+    streamed = kind == 'torch' and (not _arrays.is_torch(y) or
+                                    (x_given is not None and not _arrays.is_torch(x_given)))
+    if mask is None and not streamed:
+        yd = _arrays.to_device(y, dev)
+        if x_given is None:
+            xd = torch.ones(x.shape, dtype=Dd.dtype, device=Dd.device)
+        else:
+            xd = _arrays.to_device(x_given, dev, copy=True)
+        rng = np.random.RandomState(random_seed)                         # :85
+        it, Dout, xout = solve_cd_indexed(yd, Dd, alpha, xd, tol, minibatch, maxiter,
+                                          lasso_method, lasso_iter, lasso_tol, rng)
+        return it, _arrays.to_caller(Dout, kind), _arrays.to_caller(xout, kind)
+
     ybat = dataset(y, False)                                             # :79-80
     if x_given is None:
         xbat = MinibatchData(torch.ones(x.shape, dtype=Dd.dtype, device=Dd.device), minibatch)
@@ -88,6 +110,199 @@ def solve(y, D, alpha, x=None, tol=1.0e-3,
         it, Dout, xout = solve_cd_mask(ybat, Dd, alpha, xbat, tol, minibatch, maxiter,
                                        lasso_method, lasso_iter, lasso_tol, rng, kind, mbat)
     return it, _arrays.to_caller(Dout, kind), _arrays.to_caller(xout, kind)
+
+
+def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
+                     lasso_method, lasso_iter, lasso_tol, rng):
+    """dictionary_learning.py:114-168 for in-core data: ``y`` [N, F] and ``x`` [N, K] are device
+    arrays in their ORIGINAL row order (x is updated in place, y is only read), ``D`` a device
+    array (normalised in place).  Returns (it, D, x)."""
+    import torch
+    import time as _time
+    t_fn0 = _time.perf_counter()
+    N = y.shape[0]
+    if N < minibatch:                                                    # utils/data.py:79-82
+        raise ValueError('Minibatch size should be smaller than the total '
+                         'size. Given {} < {}'.format(N, minibatch))
+    K, F = D.shape
+    sfx = _arrays.suffix(D)
+    lib, h = _arrays.lib_handle(D)
+    step = getattr(lib, 'dcp_dict_step_async_' + sfx)
+    code = lasso._dict_method_code(lasso_method)
+    pcd_table = lasso._dict_pcd_table(lasso_method, K, lasso_iter, D)    # noqa: F841 (kept alive)
+    dev = D.device
+    rdt = torch.float32 if D.dtype in (torch.float32, torch.complex64) else torch.float64
+    A = torch.zeros((K, K), dtype=D.dtype, device=dev)                   # :122-123
+    B = torch.zeros((K, F), dtype=D.dtype, device=dev)
+    _arrays.l2_normalize_(D, strict=True)                                # :126
+    D_new = torch.empty_like(D)
+    n_loop = int(N / minibatch)                                          # utils/data.py:107-108
+    y_stage = [torch.empty((minibatch, F), dtype=y.dtype, device=dev) for _ in range(2)]
+    x_stage = torch.empty((minibatch, K), dtype=x.dtype, device=dev)
+    md_dev = torch.zeros((2,), dtype=rdt, device=dev)
+    md_host = torch.zeros((2,), dtype=rdt, pin_memory=True)
+    # two preallocated pinned blocks for the epochs' row orders, filled by a plain single-threaded copy
+    # (Tensor.pin_memory() per epoch would run torch's parallel CPU copy: on a many-core host its worker
+    # threads spin after every call and starve the launching thread of its CPU share -- measured: 50-90 ms
+    # stalls of single launches under the container's CPU quota)
+    host_blocks = [[torch.empty((n_loop * minibatch,), dtype=torch.int64, pin_memory=True), None] for _ in range(2)]
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(torch, dev)
+    # the staging blocks come from the compute stream's pool: whatever that stream still has queued on their
+    # memory (earlier temporaries of the caller) must be done before the side stream writes into them
+    side.wait_stream(main)
+    row_bytes_y = F * y.element_size()
+    row_bytes_x = K * x.element_size()
+    from .utils.data import _move_rows
+
+    def next_order(state):
+        """The next epoch's row order (host only): position p of epoch e holds original row order_e[p],
+        order_e = order_{e-1}[index] with the index shuffled in place once per epoch (utils/data.py:152-156,
+        dictionary_learning.py:131-133), written into that epoch's pinned block."""
+        index, order, block = state
+        rng.shuffle(index)
+        order = order[index]
+        block.numpy()[...] = order[:n_loop * minibatch]     # plain single-threaded copy (see host_blocks)
+        return order
+
+    def steps():
+        """(epoch number, device index of the minibatch's ORIGINAL rows, upload event), in the reference's
+        order.  The permutation of epoch e + 1 is drawn by a helper thread while epoch e computes (the main
+        thread spends its time inside the library with the GIL released): ~1.5 ms of host work per epoch at
+        65536 rows that would otherwise sit between two steps with the GPU idle.  The RNG is touched by one
+        thread at a time and in the reference's order."""
+        import concurrent.futures
+        index = np.arange(N)                                             # :120
+        order = np.arange(N)
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if maxiter > 2 else None
+        try:
+            fut = None
+            for it in range(1, maxiter):                                     # :130
+                hb = host_blocks[it & 1]
+                if fut is None:
+                    if hb[1] is not None:
+                        hb[1].synchronize()
+                    order = next_order((index, order, hb[0]))
+                else:
+                    order = fut.result()
+                with torch.cuda.stream(side):
+                    idx_dev = hb[0].to(dev, non_blocking=True)
+                    up = torch.cuda.Event()
+                    up.record(side)
+                hb[1] = up
+                # allocated in the side stream's pool, read by the compute stream's x gather / scatter too: the
+                # allocator must not hand the block to the next epoch's upload while those are still queued
+                idx_dev.record_stream(main)
+                fut = None
+                if pool is not None and it + 1 < maxiter:
+                    nb = host_blocks[(it + 1) & 1]
+                    if nb[1] is not None:
+                        nb[1].synchronize()          # the upload that last read that block (the epoch before)
+                    fut = pool.submit(next_order, (index, order, nb[0]))
+                for m in range(n_loop):
+                    yield it, idx_dev[m * minibatch:(m + 1) * minibatch], up, hb[0]
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
+
+    def fetch_y(idx, buf, stream):
+        with torch.cuda.stream(stream):
+            _move_rows('dcp_gather_rows_bytes', y, idx, minibatch, row_bytes_y, y_stage[buf])
+
+    trace = os.environ.get('DCP_DL_TRACE', '0') == '1'      # analysis knob: host seconds per phase
+    tacc = {'next_epoch_or_step': 0.0, 'gathers': 0.0, 'step_call': 0.0, 'stop_test_wait': 0.0, 'scatter': 0.0}
+    lasso_it = ctypes.c_int(0)
+    prefetch = os.environ.get('DCP_DL_PREFETCH', '1') != '0'     # analysis knob: gather on the compute stream
+    t_loop0 = _time.perf_counter()
+    gen = steps()
+    cur = next(gen, None)
+    count = 0
+    pending = None          # (event, slot, it, D_new) of the step before
+    ready = None            # side-stream event: y_stage[count & 1] holds the current step's rows
+    freed = [None, None]    # main-stream events: the step that last read y_stage[b] has been enqueued
+    keep = []               # index tensors the side stream may still be reading
+    try:
+        while cur is not None:
+            it, idx, uploaded = cur[0], cur[1], cur[2]
+            buf = count & 1
+            main.wait_event(uploaded)
+            if ready is None:
+                fetch_y(idx, buf, main)
+            else:
+                main.wait_event(ready)
+            t0 = _time.perf_counter()
+            nxt = next(gen, None)
+            t1 = _time.perf_counter()
+            tacc['next_epoch_or_step'] += t1 - t0
+            if nxt is not None and not prefetch:
+                ready = None
+            if nxt is not None and prefetch:     # rows of the NEXT step, beside this step's kernels
+                if freed[buf ^ 1] is not None:
+                    side.wait_event(freed[buf ^ 1])
+                fetch_y(nxt[1], buf ^ 1, side)
+                ready = torch.cuda.Event()
+                ready.record(side)
+                keep = keep[-3:] + [nxt]
+            _move_rows('dcp_gather_rows_bytes', x, idx, minibatch, row_bytes_x, x_stage)
+            t2 = _time.perf_counter()
+            tacc['gathers'] += t2 - t1
+            theta_plus1 = count * minibatch + 1.0                        # :143-144
+            beta = (theta_plus1 - minibatch) / theta_plus1
+            lib, h = _arrays.lib_handle(D)
+            slot = count & 1
+            rc = step(h, _arrays.ptr(y_stage[buf]), _arrays.ptr(x_stage), _arrays.ptr(D), _arrays.ptr(D_new),
+                      _arrays.ptr(A), _arrays.ptr(B), minibatch, F, K, float(beta), float(alpha), code,
+                      int(lasso_iter), float(lasso_tol), _arrays.ptr(md_dev[slot:slot + 1]),
+                      ctypes.byref(lasso_it))
+            _hip.check(h, rc, 'dcp_dict_step_async_' + sfx)
+            t3 = _time.perf_counter()
+            tacc['step_call'] += t3 - t2
+            md_host[slot:slot + 1].copy_(md_dev[slot:slot + 1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            freed[buf] = ev
+            # stop test of the PREVIOUS step (:161-162), now that this one is enqueued
+            if pending is not None:
+                pev, pslot, pit, pD = pending
+                pev.synchronize()
+                if float(md_host[pslot]) < tol:
+                    # this step ran speculatively on the converged dictionary: its codes are not
+                    # scattered, its A / B / D_new are dropped
+                    return pit, pD, x
+            t4 = _time.perf_counter()
+            tacc['stop_test_wait'] += t4 - t3
+            _move_rows('dcp_scatter_rows_bytes', x_stage, idx, minibatch, row_bytes_x, x)
+            tacc['scatter'] += _time.perf_counter() - t4
+            pending = (ev, slot, it, D_new)
+            D, D_new = D_new, D
+            count += 1
+            cur = nxt
+    except KeyboardInterrupt:                                            # :166-167
+        torch.cuda.synchronize(dev)
+        return (pending[2] if pending else 1), D, x
+    finally:
+        if trace:
+            print('setup ms %.3f loop total ms %.3f' % (1e3 * (t_loop0 - t_fn0), 1e3 * (_time.perf_counter() - t_loop0)), flush=True)
+            print('solve_cd_indexed host ms per step:', {k: round(1e3 * v / max(count, 1), 4) for k, v in tacc.items()},
+                  'steps', count, flush=True)
+        side.synchronize()      # the staging blocks return to the allocator: no prefetch may still be writing them
+    if pending is not None:
+        pev, pslot, pit, pD = pending
+        pev.synchronize()
+        if float(md_host[pslot]) < tol:
+            return pit, pD, x
+    return maxiter, D, x
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(torch, dev):
+    st = _SIDE_STREAMS.get(dev.index)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _SIDE_STREAMS[dev.index] = st
+    return st
 
 
 def solve_cd(y, D, alpha, x, tol, minibatch, maxiter,

@@ -9,10 +9,96 @@ is communicated; the stop test runs redundantly and identically on every rank.
 
 The reference has no multi-device path; the single-process semantics reproduced here are
 those of decomp/nmf_methods/batch_mu.py:8-26.
+
+Round 4: under the "nccl" process-group backend the whole loop runs INSIDE the library
+(``dcp_nmf_mu_sharded_*``): the handle owns an RCCL communicator (``attach_communicator``), the
+all-reduce is enqueued on the solver's own stream between the two halves of the step and the host
+only reads the lagged stop test -- no Python, no second stream, no event pair per step.  The Python
+loop ``mu_loop`` stays as the executable statement of the host logic (it is what the gloo tests
+drive, with an oracle-backed or HIP-backed step) and as the path for process groups RCCL cannot
+serve (several ranks on one GPU).
 """
 import ctypes
+import os
 
 from . import _arrays, _hip
+
+_COMMS = {}     # device index -> (world, rank, id(group)) of the communicator its handle holds
+
+
+def attach_communicator(device_tensor, group=None):
+    """Give this rank's library handle an RCCL communicator spanning ``group`` (collective: every
+    rank of the group must call it).  Rank 0 draws the unique id, torch.distributed carries its 128
+    bytes to the others -- the only use of that channel -- and ``dcp_comm_init`` runs
+    ncclCommInitRank on the handle's device.  Returns True when the in-library collective is usable
+    on EVERY rank, False otherwise (gloo rehearsals with several ranks per GPU, librccl missing,
+    ``DCP_SHARDED_LOOP=python``): the callers then keep the Python loop over torch.distributed."""
+    import torch
+    import torch.distributed as dist
+    lib, h = _arrays.lib_handle(device_tensor)
+    dev = device_tensor.device.index
+    init = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if init else 1
+    rank = dist.get_rank(group) if init else 0
+    key = (world, rank, id(group))
+    if _COMMS.get(dev) == key:
+        return True
+    if os.environ.get('DCP_SHARDED_LOOP', '') == 'python':
+        return False
+    if init and dist.get_backend(group) != 'nccl':
+        return False
+    ident = [None]
+    if rank == 0:
+        buf = ctypes.create_string_buffer(_hip.COMM_ID_BYTES)
+        rc = lib.dcp_comm_unique_id(buf, _hip.COMM_ID_BYTES)
+        ident = [buf.raw if rc == _hip.OK else b'']
+    if world > 1:
+        dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                   group=group)
+    ok = 0
+    if ident[0]:
+        rc = lib.dcp_comm_init(h, ident[0], rank, world)
+        ok = 1 if rc == _hip.OK else 0
+    if world > 1:       # all ranks or none
+        flag = torch.tensor([ok], dtype=torch.int32, device=device_tensor.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = int(flag.item())
+    if not ok:
+        lib.dcp_comm_destroy(h)
+        _COMMS.pop(dev, None)
+        return False
+    _COMMS[dev] = key
+    return True
+
+
+def detach_communicator(device_tensor):
+    lib, h = _arrays.lib_handle(device_tensor)
+    _hip.check(h, lib.dcp_comm_destroy(h), 'dcp_comm_destroy')
+    _COMMS.pop(device_tensor.device.index, None)
+
+
+def comm_allreduce_(t):
+    """In-place sum of a float / complex device tensor over the handle's communicator, on torch's
+    current stream (``dcp_comm_allreduce_sum_*``)."""
+    lib, h = _arrays.lib_handle(t)
+    sfx = _arrays.suffix(t)
+    n = t.numel() * (2 if sfx in ('c64', 'c128') else 1)
+    fn = lib.dcp_comm_allreduce_sum_f32 if sfx in ('f32', 'c64') else lib.dcp_comm_allreduce_sum_f64
+    _hip.check(h, fn(h, _arrays.ptr(t), n), 'dcp_comm_allreduce_sum')
+    return t
+
+
+def mu_solve_in_library(y, mask, x, D, lik, tol, maxiter):
+    """``dcp_nmf_mu_sharded_*`` on this rank's rows (x and D updated in place).  Returns it."""
+    lib, h = _arrays.lib_handle(D)
+    sfx = _arrays.suffix(D)
+    fn = getattr(lib, 'dcp_nmf_mu_sharded_' + sfx)
+    it = ctypes.c_int(0)
+    ctol = ctypes.c_float(tol) if sfx == 'f32' else ctypes.c_double(tol)
+    _hip.check(h, fn(h, _arrays.ptr(y), _arrays.ptr(mask), _arrays.ptr(x), _arrays.ptr(D), y.shape[0],
+                     y.shape[1], D.shape[0], lik, ctol, int(maxiter), ctypes.byref(it), None),
+               'dcp_nmf_mu_sharded_' + sfx)
+    return it.value
 
 
 class HipStepBackend(object):
@@ -147,6 +233,10 @@ def nmf_solve_sharded(y_local, D, x_local=None, tol=1.0e-3, maxiter=1000, likeli
     if likelihood in ['kl']:
         assertion.assert_nonnegative(y)
     _arrays.l2_normalize_(Dd, strict=True)
+    if world > 1 and attach_communicator(Dd, group):
+        # the shipped multi-GPU path: the whole loop, collective included, behind the C ABI
+        it = mu_solve_in_library(y, m, x, Dd, lik, tol, maxiter)
+        return it, Dd, x
     backend = HipStepBackend(y, m, x, Dd, lik)
     it, Dout = mu_loop(backend, Dd, tol, maxiter, group=group, world_size=world,
                        new_like=torch.empty_like)
@@ -227,7 +317,7 @@ class HipDictBackend(object):
 
 
 def dict_loop(backend, y_local, x_local, row0, n_total, D, tol, minibatch, maxiter, rng, new_like, zeros,
-              index_to_device, group=None, world_size=1):
+              index_to_device, group=None, world_size=1, allreduce=None):
     """dictionary_learning.py:114-168 with the SAMPLES sharded: rank r owns the original rows
     [row0, row0 + len(y_local)) of y and x for the whole run -- nothing but the [K, F+K] statistics
     ever crosses ranks, ONE all-reduce per minibatch step (north_star).
@@ -238,6 +328,8 @@ def dict_loop(backend, y_local, x_local, row0, n_total, D, tol, minibatch, maxit
     varies around minibatch / world_size), gathers them into a staging block, runs the LASSO and
     x^H [y | x] on it (``dcp_dict_stats_*``), scatters the new codes back into its own x, and the
     summed statistics drive the identical, redundant A/B update + atom sweep on every rank.
+    ``allreduce``: in-place sum of the statistics over the ranks; None = torch.distributed.all_reduce on
+    ``group`` (gloo rehearsals), ``comm_allreduce_`` = RCCL on the library handle's own stream.
     max|D - D_new| is read one step late (as the NMF loop does): the next minibatch is already
     enqueued when the host looks at it, and is discarded if the test had passed.
 
@@ -286,8 +378,11 @@ def dict_loop(backend, y_local, x_local, row0, n_total, D, tol, minibatch, maxit
                 stats = backend.local_stats(y_stage[:n], x_stage[:n], D)
             else:                               # this rank owns no row of the minibatch
                 stats = backend.stats.zero_()
-            if world_size > 1:
-                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)     # the ONLY collective
+            if world_size > 1:                                                # the ONLY collective
+                if allreduce is not None:       # RCCL on the handle's own stream (dcp_comm_allreduce_sum_*)
+                    allreduce(stats)
+                else:
+                    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
             theta_plus1 = count * minibatch + 1.0
             beta = (theta_plus1 - minibatch) / theta_plus1
             backend.update_async(stats, beta, A, B, D, D_new)
@@ -355,5 +450,6 @@ def dictionary_learning_sharded(y_local, D, alpha, x_local=None, tol=1.0e-3, min
     it, Dout, xout = dict_loop(
         backend, yd, xd, row0, n_total, Dd, tol, minibatch, maxiter, rng, torch.empty_like,
         lambda shape: torch.zeros(shape, dtype=Dd.dtype, device=Dd.device), index_to_device,
-        group=group, world_size=world)
+        group=group, world_size=world,
+        allreduce=comm_allreduce_ if (world > 1 and attach_communicator(Dd, group)) else None)
     return it, _arrays.to_caller(Dout, kind), _arrays.to_caller(xout, kind)

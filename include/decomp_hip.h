@@ -38,7 +38,8 @@ enum {
     DCP_ERR_NOMEM = -3,     /* workspace allocation failed */
     DCP_ERR_INTERNAL = -4,  /* library bug (workspace plan mismatch, ...) */
     DCP_ERR_UNSUPPORTED = -5,
-    DCP_ERR_REF_TYPEERROR = -6  /* the reference raises TypeError on this input (lasso.py:509) */
+    DCP_ERR_REF_TYPEERROR = -6, /* the reference raises TypeError on this input (lasso.py:509) */
+    DCP_ERR_COMM = -7       /* librccl missing, no communicator on the handle, or an RCCL call failed */
 };
 
 /* likelihood codes: decomp/nmf_methods/grads.py:7-14 */
@@ -64,6 +65,28 @@ const char* dcp_last_error_string(dcp_handle* h);
 /* compile-time facts, for the loader's sanity check */
 const char* dcp_build_info(void);
 
+/* ---- multi-GPU: the handle's RCCL communicator ---------------------------------- */
+/* The reference has no multi-device path; the data-parallel form of its loops (rows of y / x / mask
+ * sharded over one process per GPU, D replicated) needs exactly ONE exchange per outer iteration: the
+ * sum over ranks of the D-side statistics (grads.py:117-125 / dictionary_learning.py:147-152 are sums over
+ * rows).  That all-reduce runs INSIDE the library, on the handle's own stream, through RCCL over xGMI:
+ *   dcp_comm_unique_id : rank 0 draws the 128-byte id (ncclGetUniqueId) into HOST memory; the launcher's
+ *                        own channel (decomp_amd.sharded: torch.distributed's store) carries it to the
+ *                        other ranks -- the only thing that channel is used for.
+ *   dcp_comm_init      : collective over all ranks (ncclCommInitRank on the handle's device).
+ *   dcp_comm_allreduce_sum_* : in-place sum of buf[count] over the ranks, asynchronous on the handle's
+ *                        stream (complex data: pass the interleaved (re, im) floats, count doubled).
+ * librccl is bound at run time (the copy the process already holds, else the system one); without it
+ * these calls return DCP_ERR_COMM and everything else of the library works. */
+enum { DCP_COMM_ID_BYTES = 128 };
+int dcp_comm_unique_id(void* id_out, int64_t id_bytes);
+int dcp_comm_init(dcp_handle* h, const void* unique_id, int rank, int world);
+int dcp_comm_destroy(dcp_handle* h);
+/* *world = 0 when the handle has no communicator */
+int dcp_comm_info(dcp_handle* h, int* rank, int* world);
+int dcp_comm_allreduce_sum_f32(dcp_handle* h, float* buf, int64_t count);
+int dcp_comm_allreduce_sum_f64(dcp_handle* h, double* buf, int64_t count);
+
 /* ---- per-kernel timing (measurement aid, used by bench.py) ---------------------- */
 /* While enabled, every labelled kernel group of the solvers is bracketed by hipEvents on
  * the handle's stream.  dcp_profile_read synchronises the stream, folds the pending
@@ -78,7 +101,8 @@ enum {
     DCP_PROF_DUPDATE = 6,     /* (x^T x) D GEMM + quotient (or elementwise quotient) */
     DCP_PROF_DNORM = 7,       /* l2_strict + max|dD|                              */
     DCP_PROF_MISC = 8,
-    DCP_PROF_NLABELS = 9
+    DCP_PROF_EXCHANGE = 9,    /* the all-reduce of the statistics (sharded loops)  */
+    DCP_PROF_NLABELS = 10
 };
 int dcp_profile_enable(dcp_handle* h, int on);
 /* restrict the brackets to the labels whose bit is set (each bracket costs ~4 us of stream time:
@@ -153,6 +177,22 @@ int dcp_nmf_mu_f32(dcp_handle* h, const float* Y, const float* mask, float* X, f
 int dcp_nmf_mu_f64(dcp_handle* h, const double* Y, const double* mask, double* X, double* D,
                    int64_t N, int64_t F, int64_t K, int likelihood, double tol, int maxiter,
                    int* it_out, double* last_maxdiff, double* resid_trace);
+
+/* The same loop for a problem whose ROWS are sharded over the ranks of the handle's communicator
+ * (dcp_comm_init): Y, mask, X are this rank's rows, D is replicated.  Every iteration runs
+ *   local x update + [x^T Y | x^T x] (or [num | den]) on this rank's rows
+ *   -> ncclAllReduce(sum) of the [K, W] statistics on the handle's stream        (the ONLY exchange)
+ *   -> the replicated D update, l2_strict and max|D - D_new| (identical on every rank)
+ * with the stop test of iteration i read after iteration i+1 has been enqueued, exactly as in
+ * dcp_nmf_mu_*: no host synchronisation and no second stream inside a step.  Every rank must call it
+ * with the same F, K, likelihood, tol, maxiter and masked-ness; N may differ per rank.  it_out,
+ * last_maxdiff and D are identical on all ranks.  DCP_ERR_COMM without a communicator. */
+int dcp_nmf_mu_sharded_f32(dcp_handle* h, const float* Y, const float* mask, float* X, float* D,
+                           int64_t N, int64_t F, int64_t K, int likelihood, float tol, int maxiter,
+                           int* it_out, float* last_maxdiff);
+int dcp_nmf_mu_sharded_f64(dcp_handle* h, const double* Y, const double* mask, double* X, double* D,
+                           int64_t N, int64_t F, int64_t K, int likelihood, double tol, int maxiter,
+                           int* it_out, double* last_maxdiff);
 
 /* One iteration split at the data-parallel exchange point, asynchronous:
  *   dcp_nmf_mu_stats_*  : X_out <- update_x(X) (grads.py:77-84; X_out may alias X, or be a
@@ -352,6 +392,9 @@ int dcp_dict_set_pcd_order(dcp_handle* h, const int32_t* order, int64_t rows, in
  *                       the sequential atom sweep into D_new (154-159), and max|D - D_new|
  *                       into the DEVICE scalar maxdiff_dev (161).  Asynchronous.
  *   dcp_dict_step_*   : both on one GPU; max|D - D_new| returned to the HOST double.
+ *   dcp_dict_step_async_* : the same step with max|D - D_new| left in the DEVICE scalar maxdiff_dev and no
+ *                       wait for the GPU: the caller evaluates the stop test (line 161-162) one step late,
+ *                       when the next minibatch is already enqueued (decomp_amd.dictionary_learning).
  * D [K,F] must be l2_strict-normalised by the caller on entry of the run (line 126); A [K,K]
  * and B [K,F] are the running statistics (zero before the first step). */
 int dcp_dict_stats_f32(dcp_handle* h, const float* Y, float* X, const float* D, int64_t Nb, int64_t F,
@@ -362,6 +405,9 @@ int dcp_dict_update_f32(dcp_handle* h, const float* stats, double beta, float* A
 int dcp_dict_step_f32(dcp_handle* h, const float* Y, float* X, const float* D, float* D_new, float* A, float* B,
                        int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
                        int lasso_iter, double lasso_tol, double* maxdiff, int* lasso_it);
+int dcp_dict_step_async_f32(dcp_handle* h, const float* Y, float* X, const float* D, float* D_new, float* A, float* B,
+                             int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                             int lasso_iter, double lasso_tol, float* maxdiff_dev, int* lasso_it);
 /* out[i, :] = in[index[i], :]  (MinibatchData.shuffle / .array, decomp/utils/data.py:147-156);
  * index: int64 on the device. */
 int dcp_gather_rows_f32(dcp_handle* h, const float* in, const int64_t* index, int64_t rows,
@@ -374,6 +420,9 @@ int dcp_dict_update_f64(dcp_handle* h, const double* stats, double beta, double*
 int dcp_dict_step_f64(dcp_handle* h, const double* Y, double* X, const double* D, double* D_new, double* A, double* B,
                        int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
                        int lasso_iter, double lasso_tol, double* maxdiff, int* lasso_it);
+int dcp_dict_step_async_f64(dcp_handle* h, const double* Y, double* X, const double* D, double* D_new, double* A, double* B,
+                             int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                             int lasso_iter, double lasso_tol, double* maxdiff_dev, int* lasso_it);
 /* out[i, :] = in[index[i], :]  (MinibatchData.shuffle / .array, decomp/utils/data.py:147-156);
  * index: int64 on the device. */
 int dcp_gather_rows_f64(dcp_handle* h, const double* in, const int64_t* index, int64_t rows,
@@ -386,6 +435,9 @@ int dcp_dict_update_c64(dcp_handle* h, const void* stats, double beta, void* A, 
 int dcp_dict_step_c64(dcp_handle* h, const void* Y, void* X, const void* D, void* D_new, void* A, void* B,
                        int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
                        int lasso_iter, double lasso_tol, double* maxdiff, int* lasso_it);
+int dcp_dict_step_async_c64(dcp_handle* h, const void* Y, void* X, const void* D, void* D_new, void* A, void* B,
+                             int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                             int lasso_iter, double lasso_tol, float* maxdiff_dev, int* lasso_it);
 /* out[i, :] = in[index[i], :]  (MinibatchData.shuffle / .array, decomp/utils/data.py:147-156);
  * index: int64 on the device. */
 int dcp_gather_rows_c64(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
@@ -398,6 +450,9 @@ int dcp_dict_update_c128(dcp_handle* h, const void* stats, double beta, void* A,
 int dcp_dict_step_c128(dcp_handle* h, const void* Y, void* X, const void* D, void* D_new, void* A, void* B,
                        int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
                        int lasso_iter, double lasso_tol, double* maxdiff, int* lasso_it);
+int dcp_dict_step_async_c128(dcp_handle* h, const void* Y, void* X, const void* D, void* D_new, void* A, void* B,
+                             int64_t Nb, int64_t F, int64_t K, double beta, double alpha, int lasso_method,
+                             int lasso_iter, double lasso_tol, double* maxdiff_dev, int* lasso_it);
 /* out[i, :] = in[index[i], :]  (MinibatchData.shuffle / .array, decomp/utils/data.py:147-156);
  * index: int64 on the device. */
 int dcp_gather_rows_c128(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,

@@ -286,9 +286,16 @@ def test_errors():
         dl.solve(y, D, 0.1, minibatch=50)                    # minibatch > n_samples
 
 
-def _sharded_dl_problem():
+def _sharded_dl_problem(cplx=False):
     rng = np.random.RandomState(21)
     N, F, K = 240, 64, 12
+    if cplx:        # configs[4]'s form: complex64 data, complex [K, F+K] statistics through the all-reduce
+        def rn(*sh):
+            return rng.randn(*sh) + 1j * rng.randn(*sh)
+        Dt = rn(K, F)
+        xt = 3.0 * rn(N, K) * (rng.uniform(size=(N, K)) < 0.2)
+        y = (xt @ Dt + 0.1 * rn(N, F)).astype(np.complex64)
+        return y, (Dt + 0.2 * rn(K, F)).astype(np.complex64)
     Dt = rng.randn(K, F)
     xt = 3.0 * rng.randn(N, K) * (rng.uniform(size=(N, K)) < 0.2)
     y = (xt @ Dt + 0.1 * rng.randn(N, F)).astype(np.float32)
@@ -307,7 +314,7 @@ def test_sharded_dictionary_world1_equals_solve():
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
-def _dl_gloo_gpu_worker(rank, world, port, q, kw=None):
+def _dl_gloo_gpu_worker(rank, world, port, q, kw=None, cplx=False):
     import os
     import sys
     import torch.distributed as dist
@@ -317,7 +324,7 @@ def _dl_gloo_gpu_worker(rank, world, port, q, kw=None):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from decomp_amd import sharded
-        y, D0 = _sharded_dl_problem()
+        y, D0 = _sharded_dl_problem(cplx)
         lo, hi = (0, 100) if rank == 0 else (100, y.shape[0])      # unequal shards, owned for the whole run
         calls = {'n': 0}
         real = dist.all_reduce
@@ -332,19 +339,22 @@ def _dl_gloo_gpu_worker(rank, world, port, q, kw=None):
         dist.destroy_process_group()
 
 
-def test_sharded_dictionary_two_ranks_on_one_gpu_gloo():
+@pytest.mark.parametrize('cplx', [False, True])
+def test_sharded_dictionary_two_ranks_on_one_gpu_gloo(cplx):
     """Samples sharded over two processes sharing the test box's GPU (each owns its rows of y and x for
     the whole run); ONLY the [K, F+K] statistics cross ranks, one all-reduce per minibatch step over
-    gloo: must reproduce the single-process result to rounding."""
+    gloo: must reproduce the single-process result to rounding.  cplx: complex64 data -- the multi-GPU form
+    of configs[4]; the complex x^H [y | x] statistics cross the all-reduce (dictionary_learning.py:147-152)."""
     import os
     import torch.multiprocessing as mp
     from decomp_amd import dictionary_learning as dl
-    y, D0 = _sharded_dl_problem()
+    y, D0 = _sharded_dl_problem(cplx)
     it1, D1, x1 = dl.solve(y.copy(), D0.copy(), 0.02, **_DL_KW)
+    assert D1.dtype == (np.complex64 if cplx else np.float32)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29800 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_dl_gloo_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29800 + (os.getpid() % 1000) + (1000 if cplx else 0)
+    procs = [ctx.Process(target=_dl_gloo_gpu_worker, args=(r, 2, port, q, None, cplx)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])

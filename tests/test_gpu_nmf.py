@@ -172,7 +172,7 @@ def test_sharded_driver_world1_equals_solve(masked):
     assert np.array_equal(Ds.cpu().numpy(), D) and np.array_equal(xs.cpu().numpy(), x)
 
 
-def _gloo_gpu_worker(rank, world, port, q):
+def _gloo_gpu_worker(rank, world, port, q, masked=False):
     import os
     import sys
     import torch
@@ -183,27 +183,30 @@ def _gloo_gpu_worker(rank, world, port, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from decomp_amd import sharded
-        y, D0, _ = _sharded_problem()
+        y, D0, mask = _sharded_problem()
         rows = slice(rank * len(y) // world, (rank + 1) * len(y) // world)
         it, D, x = sharded.nmf_solve_sharded(torch.from_numpy(y[rows]).cuda(),
-                                             torch.from_numpy(D0).cuda(), tol=2e-3, maxiter=200)
+                                             torch.from_numpy(D0).cuda(), tol=2e-3, maxiter=200,
+                                             mask_local=torch.from_numpy(mask[rows]).cuda() if masked else None)
         q.put((rank, it, D.cpu().numpy(), x.cpu().numpy()))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_two_ranks_on_one_gpu_gloo():
+@pytest.mark.parametrize('masked', [False, True])
+def test_sharded_two_ranks_on_one_gpu_gloo(masked):
     """Two processes sharing the one GPU of the test box, statistics all-reduced over gloo:
-    the real HIP step kernels + the real collective logic with world_size = 2."""
+    the real HIP step kernels + the real collective logic with world_size = 2 (masked: the [K, 2F]
+    numerator | denominator statistics of configs[3]'s form cross the all-reduce)."""
     import os
     import torch.multiprocessing as mp
     import decomp_amd
-    y, D0, _ = _sharded_problem()
-    it1, D1, x1 = decomp_amd.nmf.solve(y, D0.copy(), tol=2e-3, maxiter=200)
+    y, D0, mask = _sharded_problem()
+    it1, D1, x1 = decomp_amd.nmf.solve(y, D0.copy(), tol=2e-3, maxiter=200, mask=mask if masked else None)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_gloo_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 1000) + (1000 if masked else 0)
+    procs = [ctx.Process(target=_gloo_gpu_worker, args=(r, 2, port, q, masked)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
@@ -265,6 +268,78 @@ def test_sharded_loop_over_rccl_world1():
     assert p.exitcode == 0
     assert it == it1
     assert np.array_equal(D, D1) and np.array_equal(x, x1)
+
+
+def _in_library_world1_worker(q, dt, masked, lik):
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.cuda.set_device(0)
+    from decomp_amd import _arrays, _hip, sharded
+    y, D0, mask = _sharded_problem()
+    tdt = torch.float32 if dt == 'f32' else torch.float64
+    Y = torch.from_numpy(y).cuda().to(tdt)
+    M = torch.from_numpy(mask).cuda().to(tdt) if masked else None
+    D = torch.from_numpy(D0).cuda().to(tdt)
+    _arrays.l2_normalize_(D, strict=True)
+    x = torch.ones((Y.shape[0], D.shape[0]), dtype=tdt, device='cuda')
+    assert sharded.attach_communicator(D), 'RCCL communicator could not be created on the GPU box'
+    lib, h = _arrays.lib_handle(D)
+    import ctypes
+    r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+    lib.dcp_comm_info(h, ctypes.byref(r), ctypes.byref(w))
+    assert (r.value, w.value) == (0, 1)
+    it = sharded.mu_solve_in_library(Y, M, x, D, _hip.LIK_KL if lik == 'kl' else _hip.LIK_L2, 2e-3, 200)
+    # the collective entry point on complex data (configs[4]'s statistics dtype): identity on one rank
+    c = torch.complex(torch.randn(37, 11, device='cuda'), torch.randn(37, 11, device='cuda'))
+    c0 = c.clone()
+    sharded.comm_allreduce_(c)
+    torch.cuda.synchronize()
+    assert torch.equal(c, c0)
+    sharded.detach_communicator(D)
+    lib.dcp_comm_info(h, ctypes.byref(r), ctypes.byref(w))
+    assert w.value == 0
+    q.put((it, D.cpu().numpy(), x.cpu().numpy()))
+
+
+@pytest.mark.parametrize('dt,masked,lik', [('f32', False, 'l2'), ('f32', True, 'l2'), ('f64', False, 'l2'),
+                                           ('f32', False, 'kl')])
+def test_in_library_sharded_loop_over_rccl_world1(dt, masked, lik):
+    """dcp_nmf_mu_sharded_*: the loop a rank of a multi-GPU run executes -- statistics, ncclAllReduce on the
+    handle's own stream (a 1-rank RCCL communicator created through dcp_comm_unique_id / dcp_comm_init: the
+    identity), replicated update, lagged stop test -- must reproduce nmf.solve bit for bit, stop iteration
+    included.  batch_mu.py:16-26."""
+    import torch.multiprocessing as mp
+    import decomp_amd
+    y, D0, mask = _sharded_problem()
+    npdt = np.float32 if dt == 'f32' else np.float64
+    it1, D1, x1 = decomp_amd.nmf.solve(y.astype(npdt), D0.astype(npdt), tol=2e-3, maxiter=200,
+                                       mask=mask.astype(npdt) if masked else None, likelihood=lik)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_in_library_world1_worker, args=(q, dt, masked, lik))
+    p.start()
+    it, D, x = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert it == it1 and 2 < it < 199
+    assert np.array_equal(D, D1) and np.array_equal(x, x1)
+
+
+def test_sharded_entry_without_communicator_is_an_error():
+    import ctypes
+    import torch
+    from decomp_amd import _arrays, _hip
+    D = torch.rand(4, 32, device='cuda')
+    Y = torch.rand(16, 32, device='cuda')
+    x = torch.ones(16, 4, device='cuda')
+    lib, h = _arrays.lib_handle(D)
+    it = ctypes.c_int(0)
+    rc = lib.dcp_nmf_mu_sharded_f32(h, _arrays.ptr(Y), None, _arrays.ptr(x), _arrays.ptr(D), 16, 32, 4, 0,
+                                    ctypes.c_float(0.0), 3, ctypes.byref(it), None)
+    assert rc == _hip.ERR_COMM
+    assert lib.dcp_comm_allreduce_sum_f32(h, _arrays.ptr(D), 8) == _hip.ERR_COMM
 
 
 @pytest.mark.parametrize('shape', [(1000, 1200, 24), (4096, 1024, 256), (333, 77, 5)])
