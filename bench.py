@@ -475,6 +475,17 @@ def secondary_configs(torch, device, with_oracle=False):
                                                                10, True)
     if c_parity is not None:
         out['complex_dictionary_step_ms']['parity'] = c_parity
+    del Yc, Dc, xc, Ac, Bc
+    # the reference's OWN benchmark shapes (speed_tests/tests/test_nmf.py:14-66, test_lasso.py:8-59), small enough
+    # that launch latency decides: the drop-in on device arrays beside the NumPy oracle on this host's cores
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('ref_speed_shapes', os.path.join(ROOT, 'tools', 'ref_speed_shapes.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        out['reference_speed_shapes'] = mod.run(with_cpu=with_oracle)
+    except Exception as e:      # a side measurement never costs the headline line
+        out['reference_speed_shapes'] = {'error': repr(e)}
     return out
 
 

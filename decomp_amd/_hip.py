@@ -64,6 +64,7 @@ SIGNATURES = {
                               _c_int, _c_int]),
     'dcp_gather_rows_bytes': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_scatter_rows_bytes': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_dict_prefetch_rows_bytes': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_dict_set_pcd_order': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64]),
     'dcp_lasso_f32': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_int, _P(_c_int)]),
     'dcp_lasso_f64': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64, _c_f64, _c_f64, _c_int, _c_int, _c_int, _P(_c_int)]),

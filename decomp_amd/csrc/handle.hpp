@@ -39,6 +39,12 @@ struct dcp_handle {
     // RCCL communicator of the sample-sharded solvers (comm.hip; ncclComm_t kept opaque here)
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    // a row gather registered by dcp_dict_prefetch_rows_bytes: the next dictionary step runs it on the side
+    // stream beside its atom sweep (rows of the NEXT minibatch while the chip is nearly idle)
+    const void* pf_in = nullptr;
+    const int64_t* pf_index = nullptr;
+    void* pf_out = nullptr;
+    int64_t pf_rows = 0, pf_row_bytes = 0;
     // parallel_cd inside the dictionary step: the caller-supplied shuffle table (dcp_dict_set_pcd_order)
     const int* pcd_order = nullptr;
     int64_t pcd_rows = 0, pcd_K = 0;
@@ -122,6 +128,10 @@ inline int main_after_side(dcp_handle* h) {
         return fail(h, DCP_ERR_HIP, "side stream join failed");
     return DCP_OK;
 }
+
+// gather / scatter rows on `stream` (util.hip; the row movers of the minibatch containers)
+int move_rows_on(dcp_handle* h, hipStream_t stream, const void* in, const int64_t* in_index, void* out,
+                 const int64_t* out_index, int64_t rows, int64_t row_bytes);
 
 inline void ws_reset(dcp_handle* h) {
     h->arena_used = 0;

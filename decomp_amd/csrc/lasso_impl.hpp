@@ -156,6 +156,125 @@ struct EpiProxStep {
     }
 };
 
+// The same step in the "H form" (no 2-D mask):  with H = I - Linv A A^H and r = Linv y A^H, both formed ONCE per
+// solve,   v + Linv (y A^H - v A A^H) = v H + r ,   so the epilogue of the v.H product reads ONE [N, K] array (r)
+// instead of three (y A^H, v, x_prev) -- x_prev is only touched when the iteration needs x_new - x_prev (momentum,
+// or the stop test of iterations 0, 10, ...).  One launch of the dictionary step's 8192 x 512 x 512 iteration is a
+// single lock-step round of workgroups (main loop, then epilogue, nothing to overlap them with), so its [N, K]
+// epilogue traffic is exposed time: 84 MB -> 34 MB per launch.  Same fixed point, same iterates up to rounding
+// (the Gram-form remark of DESIGN.md section 2 applies: a re-association of lasso.py:248-256).
+template <class T, int PROX>
+struct EpiProxStepH {
+    typedef real_t<T> R;
+    const T* rs;        // Linv * yAt
+    const T* xprev;     // read only when need_prev
+    T* xnew;
+    T* vnext;           // nullable (plain ista)
+    long ld;
+    const R* Linv;      // device scalar
+    const R* alpha;     // [K]
+    const R* tolk;      // [K]
+    R coef;
+    int check;
+    int need_prev;      // check != 0 or vnext != nullptr
+    int* flag;
+    __device__ __forceinline__ void operator()(int r, int c, T back, int) const {
+        const long i = (long)r * ld + c;
+        const T z = add(back, rs[i]);
+        const T xn = prox_apply<PROX>(z, Linv[0] * alpha[c]);
+        xnew[i] = xn;
+        if (need_prev) {
+            const T d = sub(xn, xprev[i]);
+            if (vnext != nullptr) vnext[i] = add(xn, scale(d, coef));
+            if (check && !((absval(d) - tolk[c]) < R(0))) *flag = 1;
+        }
+    }
+    static constexpr bool kVec4 = std::is_same<T, float>::value;
+    bool vec_ok() const {
+        return al16_ptr(rs) && al16_ptr(xprev) && al16_ptr(xnew) && al16_ptr(alpha) && al16_ptr(tolk) &&
+               (vnext == nullptr || al16_ptr(vnext)) && (ld % 4) == 0;
+    }
+    __device__ __forceinline__ void vec4(int r, int c0, f32x4 back, int) const {
+        if constexpr (std::is_same<T, float>::value) {
+            const long i = (long)r * ld + c0;
+            const float li = Linv[0];
+            const f32x4 r4 = *reinterpret_cast<const f32x4*>(rs + i);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(alpha + c0);
+            f32x4 xn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xn[e] = prox_apply<PROX>(back[e] + r4[e], li * a4[e]);
+            *reinterpret_cast<f32x4*>(xnew + i) = xn;
+            if (need_prev) {
+                const f32x4 p4 = *reinterpret_cast<const f32x4*>(xprev + i);
+                f32x4 vn;
+                bool viol = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = xn[e] - p4[e];
+                    vn[e] = xn[e] + d * coef;
+                    if (check && !((fabsf(d) - tolk[c0 + e]) < 0.0f)) viol = true;
+                }
+                if (vnext != nullptr) *reinterpret_cast<f32x4*>(vnext + i) = vn;
+                if (viol) *flag = 1;
+            }
+        }
+    }
+    static constexpr bool kCVec2 = std::is_same<T, c64>::value;
+    bool cvec_ok() const {
+        return al16_ptr(rs) && al16_ptr(xprev) && al16_ptr(xnew) && (vnext == nullptr || al16_ptr(vnext)) &&
+               (ld % 2) == 0;
+    }
+    __device__ __forceinline__ void cvec2(int r, int c0, f32x4 back, int) const {
+        if constexpr (std::is_same<T, c64>::value) {
+            const long i = (long)r * ld + c0;
+            const float li = Linv[0];
+            const f32x4 r4 = *reinterpret_cast<const f32x4*>(rs + i);
+            f32x4 xn4;
+            c64 xn[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const c64 z{back[2 * e] + r4[2 * e], back[2 * e + 1] + r4[2 * e + 1]};
+                xn[e] = prox_apply<PROX>(z, li * alpha[c0 + e]);
+                xn4[2 * e] = xn[e].re; xn4[2 * e + 1] = xn[e].im;
+            }
+            *reinterpret_cast<f32x4*>(xnew + i) = xn4;
+            if (need_prev) {
+                const f32x4 p4 = *reinterpret_cast<const f32x4*>(xprev + i);
+                f32x4 vn4;
+                bool viol = false;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const c64 d = sub(xn[e], c64{p4[2 * e], p4[2 * e + 1]});
+                    const c64 vn = add(xn[e], scale(d, coef));
+                    vn4[2 * e] = vn.re; vn4[2 * e + 1] = vn.im;
+                    if (check && !((absval(d) - tolk[c0 + e]) < 0.0f)) viol = true;
+                }
+                if (vnext != nullptr) *reinterpret_cast<f32x4*>(vnext + i) = vn4;
+                if (viol) *flag = 1;
+            }
+        }
+    }
+};
+
+// AAt <- I - Linv AAt (in place, [K, K]) and yAt <- Linv yAt (in place, [N, K]): the H form's two operands
+template <class T>
+__global__ void __launch_bounds__(256) hform_prepare_kernel(T* __restrict__ AAt, long K, T* __restrict__ yAt,
+                                                            long nk, const real_t<T>* __restrict__ Linv) {
+    typedef real_t<T> R;
+    const R li = Linv[0];
+    const long kk = K * K;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < kk + nk; i += (long)gridDim.x * 256L) {
+        if (i < kk) {
+            const long r = i / K, c = i - r * K;
+            T h = scale(AAt[i], -li);
+            if (r == c) h = add(h, from_real<T>(R(1)));
+            AAt[i] = h;
+        } else {
+            yAt[i - kk] = scale(yAt[i - kk], li);
+        }
+    }
+}
+
 // out = base - acc   (g = yAt - x.AAt for coordinate descent)
 template <class T>
 struct EpiSubFrom {
@@ -1041,6 +1160,12 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             DCP_TRY(gram_kk<T>(h, w.An, w.An, K, F, w, w.AAt));
         }
         DCP_TRY(gershgorin_bound<T>(h, w.AAt, K, w));
+        const bool hform = (mask_ndim != 2);
+        if (hform) {
+            hipLaunchKernelGGL((hform_prepare_kernel<T>), dim3(grid_for((long)K * K + (long)N * K)), dim3(256), 0, st,
+                               w.AAt, (long)K, w.yAt, (long)N * K, (const R*)w.scal);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+        }
 
         // Buffer roles (pointers rotate over the four [N,K] buffers):
         //   P = the iterate the stop test compares with (the reference's x0)
@@ -1119,7 +1244,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
                 a2.ext_ws = w.ext1;
                 DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a2, epi)));
             } else {
-                GemmArgs<T> a;    // back = V AAt, prox step in the epilogue
+                GemmArgs<T> a;    // back = V H (H = I - Linv A A^H, see EpiProxStepH), prox step in the epilogue
                 a.A = V; a.lda = K; a.B = w.AAt; a.ldb = K; a.M = N; a.N = K; a.K = K;
                 a.ext_ws = w.ext2;
                 // complex: the extended image of A A^H (ext2 holds nothing else during the loop) is built by
@@ -1131,7 +1256,9 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
                 // 1.64 -> 1.62 ms).  complex64 measured slower on it and keeps the automatic choice.
                 if (std::is_same<T, float>::value && K >= 512 && (long)ceil_div(N, 128) * ceil_div(K, 128) >= 128)
                     a.tile = TILE_MID;
-                DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, epi)));
+                EpiProxStepH<T, PROX> epih{w.yAt, P, Nw, mom ? Vn : (T*)nullptr, (long)K, w.scal, w.alphak, w.tolk,
+                                           coef, check, (check || mom) ? 1 : 0, w.flag};
+                DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, epih)));
             }
             if (had_pending) {   // the check iteration before this one: was its test met?  (lasso.py:293-294)
                 bool stop = false;

@@ -355,8 +355,9 @@ static bool is_device_memory(const void* p) {
     return a.type == hipMemoryTypeDevice;
 }
 
-static int move_rows(dcp_handle* h, const void* in, const int64_t* in_index, void* out,
-                     const int64_t* out_index, int64_t rows, int64_t row_bytes) {
+namespace dcp {
+int move_rows_on(dcp_handle* h, hipStream_t stream, const void* in, const int64_t* in_index, void* out,
+                 const int64_t* out_index, int64_t rows, int64_t row_bytes) {
     if (!h) return DCP_ERR_INVALID;
     if (!in || !out) return dcp::fail(h, DCP_ERR_INVALID, "null pointer");
     if (rows < 0 || row_bytes < 0) return dcp::fail(h, DCP_ERR_INVALID, "negative size");
@@ -375,7 +376,7 @@ static int move_rows(dcp_handle* h, const void* in, const int64_t* in_index, voi
     if (on_device) {
         const long cap = 8192;
         hipLaunchKernelGGL(move_rows_kernel<1>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0,
-                           h->stream, inb, ii, outb, oi, (long)rows, (long)row_bytes, (int)chunks, vec_ok);
+                           stream, inb, ii, outb, oi, (long)rows, (long)row_bytes, (int)chunks, vec_ok);
     } else {
         // One side is pinned host memory, reached over PCIe.  Waves that sit on PCIe latency clog
         // the memory pipeline of their CU: a compute workgroup sharing that CU runs several times
@@ -393,11 +394,18 @@ static int move_rows(dcp_handle* h, const void* in, const int64_t* in_index, voi
         }
         const long groups = (want + 3) / 4;
         hipLaunchKernelGGL(move_rows_kernel<4>, dim3((unsigned)(groups < 12 ? groups : 12)), dim3(1024),
-                           lds_bytes, h->stream, inb, ii, outb, oi, (long)rows, (long)row_bytes,
+                           lds_bytes, stream, inb, ii, outb, oi, (long)rows, (long)row_bytes,
                            (int)chunks, vec_ok);
     }
     DCP_HIP_OK(h, hipGetLastError());
     return DCP_OK;
+}
+}  // namespace dcp
+
+static int move_rows(dcp_handle* h, const void* in, const int64_t* in_index, void* out,
+                     const int64_t* out_index, int64_t rows, int64_t row_bytes) {
+    if (!h) return DCP_ERR_INVALID;
+    return dcp::move_rows_on(h, h->stream, in, in_index, out, out_index, rows, row_bytes);
 }
 
 extern "C" {
@@ -561,6 +569,19 @@ int dcp_gemm_c128(dcp_handle* h, int form, const void* A, const void* B, void* C
                   int64_t K, int ksplits, int tile) {
     return gemm_api<c128>(h, form, reinterpret_cast<const c128*>(A), reinterpret_cast<const c128*>(B),
                           reinterpret_cast<c128*>(C), M, N, K, ksplits, tile);
+}
+
+int dcp_dict_prefetch_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
+                                 int64_t row_bytes, void* out) {
+    if (!h) return DCP_ERR_INVALID;
+    if (rows < 0 || row_bytes < 0) return dcp::fail(h, DCP_ERR_INVALID, "negative size");
+    if (rows > 0 && row_bytes > 0 && (!in || !index || !out)) return dcp::fail(h, DCP_ERR_INVALID, "null pointer");
+    h->pf_in = in;
+    h->pf_index = index;
+    h->pf_out = out;
+    h->pf_rows = rows;
+    h->pf_row_bytes = row_bytes;
+    return DCP_OK;
 }
 
 int dcp_gather_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,

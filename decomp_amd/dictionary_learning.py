@@ -12,7 +12,8 @@ libdecomp_hip.so (``dcp_dict_step_*``, decomp_amd/csrc/dict_impl.hpp).
 In-core data (y, x on the device; the BASELINE configs) take ``solve_cd_indexed``: y is never
 permuted or copied -- the reference's cumulative shuffle (utils/data.py:152-156: a full gather of
 y and x per epoch) becomes an index, each step gathers only ITS minibatch rows into a reused
-staging block (the rows of step s+1 on a side stream while step s computes), the stop test
+staging block (the rows of step s+1 beside step s's atom sweep, where the chip is nearly
+idle: ``dcp_dict_prefetch_rows_bytes``), the stop test
 ``max|D - D_new| < tol`` (dictionary_learning.py:161-162) is read one step late so the host never
 idles the GPU, and a speculative step after a passed test is discarded.  Same minibatch
 composition, same arithmetic per step, same return values.
@@ -140,16 +141,14 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
     y_stage = [torch.empty((minibatch, F), dtype=y.dtype, device=dev) for _ in range(2)]
     x_stage = torch.empty((minibatch, K), dtype=x.dtype, device=dev)
     md_dev = torch.zeros((2,), dtype=rdt, device=dev)
-    md_host = torch.zeros((2,), dtype=rdt, pin_memory=True)
+    md_host = _pinned(torch, 'md', (2,), rdt)
     # two preallocated pinned blocks for the epochs' row orders, filled by a plain single-threaded copy
     # (Tensor.pin_memory() per epoch would run torch's parallel CPU copy: on a many-core host its worker
     # threads spin after every call and starve the launching thread of its CPU share -- measured: 50-90 ms
     # stalls of single launches under the container's CPU quota)
-    host_blocks = [[torch.empty((n_loop * minibatch,), dtype=torch.int64, pin_memory=True), None] for _ in range(2)]
+    host_blocks = [[_pinned(torch, 'idx%d' % b, (n_loop * minibatch,), torch.int64), None] for b in range(2)]
     main = torch.cuda.current_stream(dev)
     side = _side_stream(torch, dev)
-    # the staging blocks come from the compute stream's pool: whatever that stream still has queued on their
-    # memory (earlier temporaries of the caller) must be done before the side stream writes into them
     side.wait_stream(main)
     row_bytes_y = F * y.element_size()
     row_bytes_x = K * x.element_size()
@@ -171,10 +170,9 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
         thread spends its time inside the library with the GIL released): ~1.5 ms of host work per epoch at
         65536 rows that would otherwise sit between two steps with the GPU idle.  The RNG is touched by one
         thread at a time and in the reference's order."""
-        import concurrent.futures
         index = np.arange(N)                                             # :120
         order = np.arange(N)
-        pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if maxiter > 2 else None
+        pool = _helper_pool() if maxiter > 2 else None
         try:
             fut = None
             for it in range(1, maxiter):                                     # :130
@@ -202,8 +200,8 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
                 for m in range(n_loop):
                     yield it, idx_dev[m * minibatch:(m + 1) * minibatch], up, hb[0]
         finally:
-            if pool is not None:
-                pool.shutdown(wait=True)
+            if fut is not None:
+                fut.result()         # the helper must not outlive the call (it writes a pinned block of it)
 
     def fetch_y(idx, buf, stream):
         with torch.cuda.stream(stream):
@@ -218,31 +216,29 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
     cur = next(gen, None)
     count = 0
     pending = None          # (event, slot, it, D_new) of the step before
-    ready = None            # side-stream event: y_stage[count & 1] holds the current step's rows
-    freed = [None, None]    # main-stream events: the step that last read y_stage[b] has been enqueued
-    keep = []               # index tensors the side stream may still be reading
+    ready = False           # y_stage[count & 1] already holds the current step's rows (prefetched)
     try:
         while cur is not None:
             it, idx, uploaded = cur[0], cur[1], cur[2]
             buf = count & 1
             main.wait_event(uploaded)
-            if ready is None:
+            if not ready:
                 fetch_y(idx, buf, main)
-            else:
-                main.wait_event(ready)
             t0 = _time.perf_counter()
             nxt = next(gen, None)
             t1 = _time.perf_counter()
             tacc['next_epoch_or_step'] += t1 - t0
-            if nxt is not None and not prefetch:
-                ready = None
-            if nxt is not None and prefetch:     # rows of the NEXT step, beside this step's kernels
-                if freed[buf ^ 1] is not None:
-                    side.wait_event(freed[buf ^ 1])
-                fetch_y(nxt[1], buf ^ 1, side)
-                ready = torch.cuda.Event()
-                ready.record(side)
-                keep = keep[-3:] + [nxt]
+            ready = False
+            if nxt is not None and prefetch:
+                # rows of the NEXT step: registered with the library, which runs the gather beside this step's
+                # atom sweep (after its statistics product, the last reader of y_stage) and joins it before the
+                # step's last kernel -- the chip and its HBM are nearly idle there
+                main.wait_event(nxt[2])             # that minibatch's index upload
+                lib, h = _arrays.lib_handle(D)
+                _hip.check(h, lib.dcp_dict_prefetch_rows_bytes(h, _arrays.ptr(y), _arrays.ptr(nxt[1]), minibatch,
+                                                               row_bytes_y, _arrays.ptr(y_stage[buf ^ 1])),
+                           'dcp_dict_prefetch_rows_bytes')
+                ready = True
             _move_rows('dcp_gather_rows_bytes', x, idx, minibatch, row_bytes_x, x_stage)
             t2 = _time.perf_counter()
             tacc['gathers'] += t2 - t1
@@ -260,7 +256,6 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
             md_host[slot:slot + 1].copy_(md_dev[slot:slot + 1], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(main)
-            freed[buf] = ev
             # stop test of the PREVIOUS step (:161-162), now that this one is enqueued
             if pending is not None:
                 pev, pslot, pit, pD = pending
@@ -285,7 +280,7 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
             print('setup ms %.3f loop total ms %.3f' % (1e3 * (t_loop0 - t_fn0), 1e3 * (_time.perf_counter() - t_loop0)), flush=True)
             print('solve_cd_indexed host ms per step:', {k: round(1e3 * v / max(count, 1), 4) for k, v in tacc.items()},
                   'steps', count, flush=True)
-        side.synchronize()      # the staging blocks return to the allocator: no prefetch may still be writing them
+        side.synchronize()      # the index uploads: nothing of this call is left on the side stream
     if pending is not None:
         pev, pslot, pit, pD = pending
         pev.synchronize()
@@ -295,6 +290,29 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
 
 
 _SIDE_STREAMS = {}
+_PINNED = {}
+_POOL = []
+
+
+def _pinned(torch, tag, shape, dtype):
+    """Pinned host blocks are kept between calls (hipHostMalloc costs a good fraction of a millisecond, a whole
+    minibatch step's worth per solve): one per (tag, shape, dtype); a call is not re-entrant per process anyway
+    (one library handle per device)."""
+    key = (tag, tuple(shape), dtype)
+    t = _PINNED.get(key)
+    if t is None:
+        if len(_PINNED) > 16:
+            _PINNED.clear()
+        t = torch.zeros(shape, dtype=dtype, pin_memory=True)
+        _PINNED[key] = t
+    return t
+
+
+def _helper_pool():
+    if not _POOL:
+        import concurrent.futures
+        _POOL.append(concurrent.futures.ThreadPoolExecutor(max_workers=1))
+    return _POOL[0]
 
 
 def _side_stream(torch, dev):
