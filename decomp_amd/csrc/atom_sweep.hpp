@@ -178,7 +178,8 @@ constexpr int kAtomSub = 8;
 template <class T>
 __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int nb, const T* __restrict__ G,
                                                 const T* __restrict__ Wl, T* __restrict__ E,
-                                                real_t<T>* __restrict__ E_rows = nullptr) {
+                                                real_t<T>* __restrict__ E_rows = nullptr,
+                                                real_t<T>* __restrict__ E_ext = nullptr) {
     typedef typename wide_of<T>::type WT;
     typedef real_t<WT> WR;
     constexpr int BMAX = atom_blk<T>();
@@ -249,6 +250,14 @@ __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int
                                 E_rows[(2L * k) * nb + i] = en.re;
                                 E_rows[(2L * k + 1) * nb + i] = en.im;
                             }
+                        if constexpr (scalar_traits<T>::is_complex)
+                            if (E_ext) {    // real left-multiplication image [2 nb, 2 nb] (atom_fused_c64.hpp)
+                                real_t<T>* o = E_ext + (2L * k) * (2 * nb) + 2 * i;
+                                o[0] = en.re;
+                                o[1] = -en.im;
+                                o[2 * nb] = en.im;
+                                o[2 * nb + 1] = en.re;
+                            }
                     }
                 }
             }
@@ -305,7 +314,14 @@ struct AtomWs {
     real_t<T>* rows_look = nullptr;
     real_t<T>* rows_prev = nullptr;
     real_t<T>* rows_E = nullptr;
+    // complex64, K % 32 == 0, F % 64 == 0: the real images of the fused path (atom_fused_c64.hpp)
+    real_t<T>* fused_reals = nullptr;
 };
+
+inline bool atom_fused_c64_shape(int64_t F, int64_t K) { return K >= 64 && (K % 32) == 0 && F >= 64 && (F % 64) == 0; }
+inline size_t atom_fused_c64_real_count(int64_t F, int64_t K) {
+    return (size_t)2 * K * F + (size_t)4 * K * K + (size_t)64 * 2 * K + (size_t)2 * K * 64 + (size_t)64 * 64 + 256;
+}
 
 // Gram slabs: up to 64 split-K slabs of the generic path, or one per 64-column tile of the fused float path
 inline size_t atom_slab_elems(int64_t F) {
@@ -331,6 +347,7 @@ inline void atom_plan(WsPlan& p, int64_t F, int64_t K) {
         p.add<real_t<T> >((size_t)2 * K * kAtomBlkMax);
         p.add<real_t<T> >((size_t)2 * kAtomBlkMax * kAtomBlkMax);
     }
+    if (std::is_same<T, c64>::value && atom_fused_c64_shape(F, K)) p.add<real_t<T> >(atom_fused_c64_real_count(F, K));
 }
 
 template <class T>
@@ -356,6 +373,10 @@ inline int atom_carve(dcp_handle* h, AtomWs<T>& w, int64_t F, int64_t K) {
         w.rows_E = ws_alloc<real_t<T> >(h, (size_t)2 * kAtomBlkMax * kAtomBlkMax);
         if (!w.rows_blk || !w.rows_look || !w.rows_prev || !w.rows_E)
             return fail(h, DCP_ERR_INTERNAL, "atom sweep workspace plan");
+    }
+    if (std::is_same<T, c64>::value && atom_fused_c64_shape(F, K)) {
+        w.fused_reals = ws_alloc<real_t<T> >(h, atom_fused_c64_real_count(F, K));
+        if (!w.fused_reals) return fail(h, DCP_ERR_INTERNAL, "atom sweep workspace plan");
     }
     if (!w.Ablk || !w.Alook || !w.Aprev || !w.P || !w.G || !w.E || !w.Wl || !w.rden || !w.slabs)
         return fail(h, DCP_ERR_INTERNAL, "atom sweep workspace plan");

@@ -13,6 +13,7 @@
 #pragma once
 #include "atom_sweep.hpp"
 #include "atom_fused_f32.hpp"
+#include "atom_fused_c64.hpp"
 #include "lasso_impl.hpp"
 
 namespace dcp {
@@ -266,6 +267,13 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
             DCP_TRY(atom_sweep_fused_f32(h, w.padA, w.padB, w.padD, Fp, Kp, w.atom));
             DCP_HIP_OK(h, hipMemcpy2DAsync(Dnew, sizeof(T) * F, w.padD, sizeof(T) * Fp, sizeof(T) * F, K,
                                            hipMemcpyDeviceToDevice, st));
+            fused = true;
+        }
+    }
+    if constexpr (std::is_same<T, c64>::value) {
+        static const bool generic_only = getenv("DCP_ATOM_GENERIC") != nullptr;    // analysis knob
+        if (!generic_only && atom_fused_c64_ok(F, K) && w.atom.fused_reals != nullptr) {
+            DCP_TRY(atom_sweep_fused_c64(h, A, B, Dnew, F, K, w.atom));
             fused = true;
         }
     }
