@@ -124,6 +124,7 @@ SIGNATURES = {
     'dcp_inv_f64': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_inv_c64': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
     'dcp_inv_c128': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp]),
+    'dcp_debug_tn_plain': (_c_int, [_c_int]),
     'dcp_calib_read_f32': (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_int, _c_vp]),
     'dcp_gemm_c64': (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_i64, _c_i64, _c_i64,
                               _c_int, _c_int]),

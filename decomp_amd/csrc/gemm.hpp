@@ -373,7 +373,20 @@ inline int plan_deep_nt(GemmArgs<T>& a, int max_s) {
     return a.ksplits;
 }
 
-inline bool tn_plain_schedule() { return getenv("DCP_TN_PLAIN") != nullptr; }
+// A/B knob of the pair schedule (TileCfg PIPE = 3): -1 = not yet read, 0 = pair schedule, 1 = plain schedule.
+// Read ONCE from DCP_TN_PLAIN; dcp_debug_tn_plain() (test hook) overrides it so that one process can run both.
+inline std::atomic<int>& tn_plain_flag() {
+    static std::atomic<int> flag{-1};
+    return flag;
+}
+inline bool tn_plain_schedule() {
+    int v = tn_plain_flag().load(std::memory_order_relaxed);
+    if (v < 0) {
+        v = getenv("DCP_TN_PLAIN") != nullptr ? 1 : 0;
+        tn_plain_flag().store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
 
 template <int FORM, class T, class Epi>
 inline hipError_t gemm(hipStream_t stream, const GemmArgs<T>& a, const Epi& epi) {

@@ -310,11 +310,11 @@ __device__ __forceinline__ f32x4 panel_frag16(const float* s, int row, int q) {
 typedef float pair_f32x2 __attribute__((ext_vector_type(2)));
 template <int OFF>
 __device__ __forceinline__ void lds_read_b64_at(pair_f32x2& d, unsigned lds_addr) {
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(lds_addr), "i"(OFF));
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(lds_addr), "i"(OFF) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void lds_wait_pair(pair_f32x2& a, pair_f32x2& b) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const float* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p;

@@ -45,6 +45,9 @@ struct dcp_handle {
     const int64_t* pf_index = nullptr;
     void* pf_out = nullptr;
     int64_t pf_rows = 0, pf_row_bytes = 0;
+    // coordinate descent: the previous solve on this handle met its stop test at sweep 0 (a warm-started,
+    // already converged problem): the next one launches that check sweep alone before committing to nine more
+    bool cd_warm = false;
     // parallel_cd inside the dictionary step: the caller-supplied shuffle table (dcp_dict_set_pcd_order)
     const int* pcd_order = nullptr;
     int64_t pcd_rows = 0, pcd_K = 0;
@@ -138,9 +141,9 @@ inline void ws_reset(dcp_handle* h) {
 }
 
 // The arena's previous user may still be running on another stream: the current stream waits for it
-// (an event, no host sync).  If the event cannot be recorded -- the previous stream was destroyed by
-// the caller, which decomp_hip.h forbids while work of this handle may be pending on it -- fall back to
-// a device synchronisation rather than fail or race.
+// (an event recorded on the previous stream, no host sync).  decomp_hip.h makes the caller keep that stream
+// alive until this point; the device synchronisation below only covers a FAILED record / wait on a live
+// stream (it is not a defence against a destroyed one: that is a use-after-free inside the runtime).
 inline void ws_order_streams(dcp_handle* h) {
     if (h->arena_stream_set && h->arena_stream != h->stream && h->arena != nullptr) {
         bool ok = false;

@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
             int cursor = 0;   // lanes < cursor of this slot are final for this sweep
             while (true) {
                 // candidate step of every lane's coordinate against the current g
-                const T z = add(g[m], mul(x[m], akk[m]));
+                const T z = fmadd(g[m], x[m], akk[m]);
                 const T xn = prox_apply<PROX>(z, al[m]);
                 const T d = sub(xn, x[m]);
                 const bool moves = (lane >= cursor) && (lane < kend) && (abs2(d) != R(0));
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
 #pragma unroll
                 for (int mm = 0; mm < MAXM; ++mm) {
                     const int c = lane + 64 * mm;
-                    const T gn = sub(g[mm], mul(dk, ar[mm]));
+                    const T gn = fmsub(g[mm], dk, ar[mm]);
                     g[mm] = (mm < M && c < K) ? gn : g[mm];
                 }
                 cursor = kk + 1;
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) cd_gram_wide_kernel(T* __restrict__ X, T*
             const int kend = min(64, K - 64 * m);
             int cursor = 0;
             while (true) {
-                const T z = add(g, mul(x, akk));
+                const T z = fmadd(g, x, akk);
                 const T xn = prox_apply<PROX>(z, al);
                 const T d = sub(xn, x);
                 const bool moves = (lane >= cursor) && (lane < kend) && (abs2(d) != R(0));
@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(256) cd_gram_wide_kernel(T* __restrict__ X, T*
                     if (check && !((absval(d) - tl) < R(0))) viol = true;
                 }
                 const T* arow = AAt + (long)(64 * m + kk) * K;
-                g = ok ? sub(g, mul(dk, arow[cc])) : g;          // this slot: the register copy
+                g = ok ? fmsub(g, dk, arow[cc]) : g;          // this slot: the register copy
                 for (int m0 = 0; m0 < M; m0 += 8) {               // the other slots: in memory
                     T ar[8], gg[8];
 #pragma unroll
@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(256) cd_gram_wide_kernel(T* __restrict__ X, T*
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int c = lane + 64 * (m0 + u);
-                        if (m0 + u < M && m0 + u != m && c < K) grow[c] = sub(gg[u], mul(dk, ar[u]));
+                        if (m0 + u < M && m0 + u != m && c < K) grow[c] = fmsub(gg[u], dk, ar[u]);
                     }
                 }
                 cursor = kk + 1;
@@ -1072,20 +1072,20 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         // codes after the check sweep are parked in a snapshot, the flag is read after the launch: when the test
         // had passed, the snapshot is the answer and the extra sweeps (nearly free on converged codes: every
         // step is a skipped zero step) are dropped.  Before: two launches and a host round trip per ten sweeps.
+        // A solve that meets the test at sweep 0 (warm start on converged codes: second visits of a minibatch with a
+        // loose lasso_tol) would still pay for the nine extra sweeps -- |dx| < tol is not dx = 0, so they are NOT
+        // free there.  When the previous solve on this handle ended that way, the check sweep is
+        // launched alone first and the other nine follow only if its test failed.
         T* snap_buf = w.xb[1];
         int sweep = 0;
         result = xcur;
-        while (sweep < maxiter) {
-            int last = sweep + 9;
-            if (last > maxiter - 1) last = maxiter - 1;
-            const int ns = last - sweep + 1;
-            T* snap = ns > 1 ? snap_buf : (T*)nullptr;
-            DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
-            const int grid = (N + 3) / 4;
+        bool met = false;
+        const int grid = (N + 3) / 4;
+        auto launch = [&](int ns, int check_first, T* snap) -> int {
 #define DCP_CD_LAUNCH(MM)                                                                            \
     hipLaunchKernelGGL((cd_gram_kernel<T, PROX, MM>), dim3(grid), dim3(256), 0, st, xcur, w.G,       \
-                       (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns, 1,     \
-                       w.flag, snap)
+                       (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,        \
+                       check_first, w.flag, snap)
             // (the register form holds a row's K coefficients in one wave: 64 lanes x up to 32 slots;
             //  wider dictionaries take the memory-resident form -- the reference has no limit, lasso.py:526-552)
             if (K <= 64) DCP_CD_LAUNCH(1);
@@ -1096,19 +1096,32 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             else if (K <= cd_register_limit()) DCP_CD_LAUNCH(32);
             else
                 hipLaunchKernelGGL((cd_gram_wide_kernel<T, PROX>), dim3(grid), dim3(256), 0, st, xcur, w.G,
-                                   (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns, 1,
-                                   w.flag, snap);
+                                   (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,
+                                   check_first, w.flag, snap);
 #undef DCP_CD_LAUNCH
             DCP_LAUNCH_OK(h, hipGetLastError());
+            return DCP_OK;
+        };
+        while (sweep < maxiter) {
+            int last = sweep + 9;
+            if (last > maxiter - 1) last = maxiter - 1;
+            const bool alone = (sweep == 0 && h->cd_warm && last > sweep);   // the check sweep on its own first
+            const int ns = alone ? 1 : last - sweep + 1;
+            T* snap = ns > 1 ? snap_buf : (T*)nullptr;
+            DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
+            DCP_TRY(launch(ns, 1, snap));
             bool viol = true;
             DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
             if (!viol) {
                 it = sweep;
                 result = snap != nullptr ? snap : xcur;
+                met = true;
                 break;
             }
+            if (alone) DCP_TRY(launch(last - sweep, 0, (T*)nullptr));        // sweeps 1 .. last, no test among them
             sweep = last + 1;
         }
+        h->cd_warm = met && it == 0;
     } else if (method == DCP_LASSO_CD) {
         // ---------------- coordinate descent with a 2-D mask (as written) ----------------
         {   // r = y o M - (x An) o M

@@ -73,6 +73,27 @@ template <class R> DCP_HD cx<R> msub(cx<R> acc, cx<R> a, cx<R> b) {
     return acc;
 }
 
+// acc + a*b and acc - a*b as EXPLICIT fused multiply-adds in a fixed order (complex: re = fma(-a.im, b.im,
+// fma(a.re, b.re, acc.re)), im = fma(a.im, b.re, fma(a.re, b.im, acc.im))): the compiler's own contraction of
+// mul + add depends on the surrounding code, these do not -- two kernels that must agree bit for bit (the register
+// and the memory-resident coordinate-descent sweeps) use them.
+DCP_HD float  fmadd(float acc, float a, float b)    { return fmaf(a, b, acc); }
+DCP_HD double fmadd(double acc, double a, double b) { return fma(a, b, acc); }
+DCP_HD c64 fmadd(c64 acc, c64 a, c64 b) {
+    return c64{fmaf(-a.im, b.im, fmaf(a.re, b.re, acc.re)), fmaf(a.im, b.re, fmaf(a.re, b.im, acc.im))};
+}
+DCP_HD c128 fmadd(c128 acc, c128 a, c128 b) {
+    return c128{fma(-a.im, b.im, fma(a.re, b.re, acc.re)), fma(a.im, b.re, fma(a.re, b.im, acc.im))};
+}
+DCP_HD float  fmsub(float acc, float a, float b)    { return fmaf(-a, b, acc); }
+DCP_HD double fmsub(double acc, double a, double b) { return fma(-a, b, acc); }
+DCP_HD c64 fmsub(c64 acc, c64 a, c64 b) {
+    return c64{fmaf(a.im, b.im, fmaf(-a.re, b.re, acc.re)), fmaf(-a.im, b.re, fmaf(-a.re, b.im, acc.im))};
+}
+DCP_HD c128 fmsub(c128 acc, c128 a, c128 b) {
+    return c128{fma(a.im, b.im, fma(-a.re, b.re, acc.re)), fma(-a.im, b.re, fma(-a.re, b.im, acc.im))};
+}
+
 DCP_HD float  conj_of(float a)  { return a; }
 DCP_HD double conj_of(double a) { return a; }
 template <class R> DCP_HD cx<R> conj_of(cx<R> a) { return cx<R>{a.re, -a.im}; }

@@ -410,6 +410,12 @@ static int move_rows(dcp_handle* h, const void* in, const int64_t* in_index, voi
 
 extern "C" {
 
+int dcp_debug_tn_plain(int on) {
+    const int prev = dcp::tn_plain_schedule() ? 1 : 0;
+    if (on >= 0) dcp::tn_plain_flag().store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
+
 int dcp_calib_read_f32(dcp_handle* h, const float* p, int64_t rows, int64_t cols, int pattern,
                        float* out) {
     if (!h) return DCP_ERR_INVALID;

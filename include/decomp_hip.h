@@ -56,10 +56,12 @@ int dcp_create(dcp_handle** out, int device);
 int dcp_destroy(dcp_handle* h);
 /* hipStream_t passed as void*; NULL = the device's default stream.  Cheap (no HIP call): the library's
  * workspace is ordered between the old and the new stream by the next call that uses workspace (an event
- * wait on the device, no host synchronisation); the row movers use none and are never ordered against
- * other streams' work.  LIFETIME: a stream handed to the handle must stay alive until work enqueued on it
- * through this handle has completed or a later workspace-using call on another stream has been issued
- * (if its event can no longer be recorded the library falls back to a device synchronisation). */
+ * recorded on the OLD stream and waited for on the new one, no host synchronisation); the row movers use none
+ * and are never ordered against other streams' work.
+ * LIFETIME (hard rule): a stream handed to the handle must stay alive until the next workspace-using call has
+ * been issued through this handle on another stream (that call still records an event on the old stream), or
+ * until the handle is destroyed.  Destroying it earlier is a use-after-free inside the HIP runtime, not an
+ * error the library can detect or recover from. */
 int dcp_set_stream(dcp_handle* h, void* hip_stream);
 const char* dcp_last_error_string(dcp_handle* h);
 /* compile-time facts, for the loader's sanity check */
@@ -155,6 +157,13 @@ int dcp_gemm_c64(dcp_handle* h, int form, const void* A, const void* B, void* C,
                  int64_t M, int64_t N, int64_t K, int ksplits, int tile);
 int dcp_gemm_c128(dcp_handle* h, int form, const void* A, const void* B, void* C,
                   int64_t M, int64_t N, int64_t K, int ksplits, int tile);
+
+/* Test hook (not a reference interface): the reduction-over-samples products (form 2) run the "pair" LDS schedule
+ * of the fp32 MFMA core unless DCP_TN_PLAIN is set in the environment (read once); on != 0 selects the plain
+ * schedule, on == 0 the pair schedule, on < 0 only queries.  Returns the previous setting (1 = plain).  Process-wide;
+ * tests/test_gpu_gemm.py runs the same products both ways so that a toolchain change that breaks the hand-placed
+ * LDS waits of the pair schedule is caught. */
+int dcp_debug_tn_plain(int on);
 
 /* PMC calibration aid (not a reference interface): reads p[rows, cols] exactly once with the
  * global-load shape of the GEMM panel loaders (pattern 0: 16 rows x 64 B per wave instruction;

@@ -204,3 +204,55 @@ def test_random_shapes_auto_dispatch(dtype):
         C = gemm_hip(form, A, B, ksplits=ks, tile=0)
         err = np.abs(C - ref) / (bound + 1e-300)
         assert err.max() < tol, (dtype, form, M, N, K, ks, float(err.max()))
+
+
+def _tn_plain(on):
+    from decomp_amd import _hip
+    return _hip.load().dcp_debug_tn_plain(int(on))
+
+
+def test_tn_pair_schedule_equals_plain_schedule():
+    """the pair schedule (TileCfg PIPE = 3) of the reduction-over-samples products rests on hand-placed
+    LDS reads and counted waits in inline asm.  The same products -- aligned, ragged, split-K, and the two-segment
+    [Y | x] operand with an ODD seam through the NMF statistics -- run with the pair schedule and with the plain
+    schedule (dcp_debug_tn_plain) and must agree to rounding level with each other and with float64: a toolchain
+    change that breaks the asm ordering shows up here."""
+    import ctypes
+    import torch
+    from decomp_amd import _arrays, _hip
+    rng = np.random.RandomState(5)
+    prev = _tn_plain(-1)
+    try:
+        for (M, N, K, ks, tile) in [(256, 4352, 8192, 15, 1), (130, 258, 1035, 1, 1), (512, 1088, 4096, 4, 0),
+                                    (512, 4608, 8192, 7, 0), (128, 128, 48, 1, 1), (64, 200, 999, 3, 1)]:
+            A, B = _operands(2, M, N, K, np.float32, rng)
+            _tn_plain(0)
+            C_pair = gemm_hip(2, A, B, ksplits=ks, tile=tile)
+            _tn_plain(1)
+            C_plain = gemm_hip(2, A, B, ksplits=ks, tile=tile)
+            bound = gemm_bound(2, A, B)
+            assert (np.abs(C_pair - gemm_ref(2, A, B)) / bound).max() < 2e-5, (M, N, K)
+            assert (np.abs(C_pair - C_plain) / bound).max() < 2e-6, (M, N, K)
+        # two-segment B = [Y | x] with an odd seam (F = 1201) and ragged rows, through dcp_nmf_mu_stats_f32
+        N, F, K = 1003, 1201, 24
+        Y = torch.rand((N, F), device='cuda')
+        D = torch.rand((K, F), device='cuda') + 0.1
+        x = torch.rand((N, K), device='cuda') + 0.1
+        lib, h = _arrays.lib_handle(D)
+        W = lib.dcp_nmf_mu_stats_width(F, K, 0, 0)
+        out = []
+        for plain in (0, 1):
+            _tn_plain(plain)
+            stats = torch.zeros((K, W), device='cuda')
+            xo = torch.empty_like(x)
+            _hip.check(h, lib.dcp_nmf_mu_stats_f32(h, _arrays.ptr(Y), None, _arrays.ptr(x), _arrays.ptr(xo),
+                                                   _arrays.ptr(D), N, F, K, 0, _arrays.ptr(stats)), 'stats')
+            out.append((stats.cpu().numpy().astype(np.float64), xo.cpu().numpy().astype(np.float64)))
+        assert np.array_equal(out[0][1], out[1][1])                     # the x update does not depend on the knob
+        xn, Yn = out[0][1], Y.cpu().numpy().astype(np.float64)
+        ref = np.concatenate([xn.T @ Yn, xn.T @ xn], axis=1)
+        scale = np.abs(ref).max()
+        assert np.abs(out[0][0] - ref).max() / scale < 2e-5
+        assert np.abs(out[0][0] - out[1][0]).max() / scale < 2e-6
+    finally:
+        _tn_plain(prev)

@@ -124,3 +124,25 @@ def test_admm_rho_keyword_and_nnls_wrapper():
     it3, x3 = lasso.solve(y, A, 0.1, tol=1e-8, method='admm_pos', maxiter=500)
     # admm returns the unconstrained iterate x (not z): non-negative only up to the tolerance
     assert it2 == it3 and np.array_equal(x2, x3) and np.all(x2 > -1e-6)
+
+
+def test_masked_admm_system_larger_than_64_kib_of_lds():
+    """with a 2-D mask ADMM solves one K x K system per row (lasso.py:620-657); the batched Gauss-Jordan
+    and the masked step keep a row's pivot data in LDS, raised up to the CU's 160 KiB (the header advertises
+    K <= 10240 real / 5120 complex).  K = 2112 complex128 needs > 64 KiB: two rows (71 MB each) against the oracle."""
+    from decomp_amd import lasso
+    from oracle import lasso as olasso
+    rng = np.random.RandomState(8)
+    N, F, K = 2, 48, 2112
+
+    def randn(*s):
+        return rng.randn(*s) + 1j * rng.randn(*s)
+    A = randn(K, F).astype(np.complex128)
+    xt = randn(N, K) * (rng.uniform(size=(N, K)) < 0.01)
+    y = (xt @ A + 0.05 * randn(N, F)).astype(np.complex128)
+    mask = np.rint(rng.uniform(0.4, 1.0, size=(N, F)))
+    it, x = lasso.solve(y.copy(), A.copy(), 0.05, tol=1e-12, method='admm', maxiter=6, mask=mask.copy())
+    ito, xo = olasso.solve(y.copy(), A.copy(), 0.05, tol=1e-12, method='admm', maxiter=6, mask=mask.copy())
+    assert it == ito == 5
+    assert x.dtype == y.dtype and x.shape == (N, K)
+    assert _err(x, xo) < 1e-8, _err(x, xo)
