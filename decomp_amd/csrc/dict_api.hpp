@@ -65,6 +65,7 @@ inline int dict_lasso(dcp_handle* h, const T* Y, const real_t<T>* M, int mask_nd
     const bool positive = (lasso_method & DCP_LASSO_POSITIVE) != 0;
     LassoExtra extra;
     extra.no_final_sync = true;            // the statistics product follows on the same stream
+    extra.start_prefetch = false;          // the prefetch runs beside the atom sweep (dict_step_core)
     if (base == DCP_LASSO_PARALLEL_CD) {   // the RNG stream of lasso.py:463,481 (dcp_dict_set_pcd_order)
         if (!h->pcd_order || h->pcd_K != K || h->pcd_rows < lasso_iter)
             return fail(h, DCP_ERR_INVALID, "parallel_cd inside the dictionary step: call "
@@ -179,18 +180,16 @@ inline int dict_step_core(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, 
     // are summed by the A / B accumulation itself
     DCP_TRY(dict_stats_core<T>(h, Y, X, D, Nb, F, K, alpha, lasso_method, lasso_iter, lasso_tol, (T*)nullptr,
                                lasso_it, lw, dw, /*keep_slabs=*/true));
-    // a registered prefetch (dcp_dict_prefetch_rows_bytes: the NEXT minibatch's rows): the statistics product
-    // above was the last reader of this step's staging block and the atom sweep below leaves the chip and its
-    // HBM nearly idle -- the gather runs beside it on the side stream and is joined before the step ends
-    const bool prefetch = h->pf_rows > 0 && h->pf_row_bytes > 0;
-    if (prefetch) {
-        DCP_TRY(side_after_main(h));
-        DCP_TRY(move_rows_on(h, h->side, h->pf_in, h->pf_index, h->pf_out, nullptr, h->pf_rows, h->pf_row_bytes));
-        h->pf_rows = 0;
-    }
+    // a registered prefetch (dcp_dict_prefetch_rows_bytes: the NEXT minibatch's rows into the OTHER staging block)
+    // runs on the side stream beside the atom sweep, where the chip and its HBM are nearly idle (beside the LASSO's
+    // iterations it measured 1 % slower, LassoExtra::start_prefetch); joined before the step's last kernel.
+    DCP_TRY(start_registered_prefetch(h));
     R* md = maxdiff_dev ? maxdiff_dev : dw.scal;
     DCP_TRY(dict_update<T>(h, dw.slabs, (R)beta, A, B, D, Dnew, F, K, md, dw, dw.stat_nslabs));
-    if (prefetch) DCP_TRY(main_after_side(h));
+    if (h->pf_inflight) {
+        DCP_TRY(main_after_side(h));
+        h->pf_inflight = false;
+    }
     if (scal_out) *scal_out = md;
     return DCP_OK;
 }

@@ -45,6 +45,7 @@ struct dcp_handle {
     const int64_t* pf_index = nullptr;
     void* pf_out = nullptr;
     int64_t pf_rows = 0, pf_row_bytes = 0;
+    bool pf_inflight = false;   // started on the side stream, not yet joined
     // coordinate descent: the previous solve on this handle met its stop test at sweep 0 (a warm-started,
     // already converged problem): the next one launches that check sweep alone before committing to nine more
     bool cd_warm = false;

@@ -842,7 +842,21 @@ struct LassoExtra {
     // the caller enqueues more work on the same stream right behind the solve (the dictionary step's x^H [y | x]
     // product): skip the stream synchronisation at the end -- *it_out is known on the host without it
     bool no_final_sync = false;
+    // start the dictionary step's registered row prefetch (dcp_dict_prefetch_rows_bytes) right behind the y.A^H
+    // product, beside the solver's iterations.  Measured (round 4, configs[2] end to end): 1.720 ms / step against
+    // 1.699 when it runs beside the atom sweep instead -- the dictionary step leaves it off.
+    bool start_prefetch = false;
 };
+
+// Starts the handle's registered row gather on the side stream, ordered after what is on the main stream now.
+inline int start_registered_prefetch(dcp_handle* h) {
+    if (h->pf_rows <= 0 || h->pf_row_bytes <= 0) return DCP_OK;
+    DCP_TRY(side_after_main(h));
+    DCP_TRY(move_rows_on(h, h->side, h->pf_in, h->pf_index, h->pf_out, nullptr, h->pf_rows, h->pf_row_bytes));
+    h->pf_rows = 0;
+    h->pf_inflight = true;
+    return DCP_OK;
+}
 
 // solve_fastpath (lasso.py:97-189).  Y [N,F], A [K,F], X [N,K] (in: initial estimate, out:
 // solution), mask: null, [F] (mask_ndim 1) or [N,F] (mask_ndim 2).  *it_out as the reference.
@@ -911,6 +925,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a, EpiStore<T>{w.yAt, K})));
         }
     }
+    if (extra.start_prefetch) DCP_TRY(start_registered_prefetch(h));
     const R* rowscale = mask_ndim == 2 ? w.rowscale : nullptr;
     int it = maxiter - 1;
     T* result = xcur;

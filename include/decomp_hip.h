@@ -386,10 +386,10 @@ int dcp_scatter_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, 
                            int64_t row_bytes, void* out);
 
 /* Registers ONE row gather (out[i, :] = in[index[i], :], as dcp_gather_rows_bytes) that the NEXT dcp_dict_step_*
- * / dcp_dict_step_async_* call on this handle runs beside its atom sweep, on the library's side stream, after its
- * statistics product (the last reader of that step's own minibatch block, so `out` may even be that block) and
- * joined before the step's last kernel: the rows of minibatch s + 1 are staged while step s leaves the chip nearly
- * idle (decomp/utils/data.py:152-156 gathers all of y once per epoch instead).  Everything enqueued on the
+ * / dcp_dict_step_async_* call on this handle runs on the library's side stream beside its atom sweep (after its
+ * statistics product, joined before the step's last kernel): the rows of minibatch s + 1 are staged while step s
+ * leaves the chip and its HBM nearly idle (decomp/utils/data.py:152-156 gathers all of y once per epoch instead).
+ * Use a second staging block for `out`.  Everything enqueued on the
  * handle's stream after that step sees the gathered rows.  rows = 0 clears a pending registration. */
 int dcp_dict_prefetch_rows_bytes(dcp_handle* h, const void* in, const int64_t* index, int64_t rows,
                                  int64_t row_bytes, void* out);
