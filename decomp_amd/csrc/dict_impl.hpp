@@ -47,9 +47,13 @@ __global__ void __launch_bounds__(256) dict_accumulate_kernel(const T* __restric
 template <class T>
 __global__ void __launch_bounds__(256) dict_accumulate_slabs_kernel(const T* __restrict__ slabs, long stride, int S,
                                                                     long K, long F, real_t<T> beta,
-                                                                    T* __restrict__ A, T* __restrict__ B) {
+                                                                    T* __restrict__ A, T* __restrict__ B,
+                                                                    const T* __restrict__ Dsrc, T* __restrict__ Ddst) {
     const long W = F + K;
     const long n = K * W;
+    // (the sweep works in place on a copy of D: the copy rides along, one launch fewer)
+    if (Dsrc != nullptr)
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < K * F; i += (long)gridDim.x * 256L) Ddst[i] = Dsrc[i];
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
         T v = slabs[i];
         int s = 1;
@@ -239,14 +243,16 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
                        int64_t F, int64_t K, real_t<T>* maxdiff_dev, DictWs<T>& w, int stats_nslabs = 0) {
     typedef real_t<T> R;
     hipStream_t st = h->stream;
-    if (stats_nslabs > 0)   // `stats` = ordered split-K partials (one GPU): sum and accumulate in one pass
+    if (stats_nslabs > 0) {  // `stats` = ordered split-K partials (one GPU): sum and accumulate in one pass
         hipLaunchKernelGGL((dict_accumulate_slabs_kernel<T>), dim3(grid_for((long)K * (F + K))), dim3(256), 0, st,
-                           stats, (long)K * (F + K), stats_nslabs, (long)K, (long)F, beta, A, B);
-    else
+                           stats, (long)K * (F + K), stats_nslabs, (long)K, (long)F, beta, A, B, D, Dnew);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+    } else {
         hipLaunchKernelGGL((dict_accumulate_kernel<T>), dim3(grid_for((long)K * (F + K))), dim3(256), 0, st,
                            stats, (long)K, (long)F, beta, A, B);
-    DCP_LAUNCH_OK(h, hipGetLastError());
-    DCP_HIP_OK(h, hipMemcpyAsync(Dnew, D, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice, st));
+        DCP_LAUNCH_OK(h, hipGetLastError());
+        DCP_HIP_OK(h, hipMemcpyAsync(Dnew, D, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice, st));
+    }
     // blocked atom sweep (float32 with K, F multiples of 64: the fused three-launch path)
     bool fused = false;
     if constexpr (std::is_same<T, float>::value) {

@@ -178,11 +178,21 @@ struct EpiProxStepH {
     int check;
     int need_prev;      // check != 0 or vnext != nullptr
     int* flag;
+    // last iteration of a solve that returns its latest iterate (ista, fista): x_new / s goes straight to the
+    // caller's array (lasso.py:189), one elementwise pass fewer
+    T* xfinal = nullptr;
+    const R* sdiv = nullptr;
+    __device__ __forceinline__ static T unscale(T v, R sk) {
+        if constexpr (scalar_traits<T>::is_complex) { v.re = v.re / sk; v.im = v.im / sk; }
+        else v = v / sk;
+        return v;
+    }
     __device__ __forceinline__ void operator()(int r, int c, T back, int) const {
         const long i = (long)r * ld + c;
         const T z = add(back, rs[i]);
         const T xn = prox_apply<PROX>(z, Linv[0] * alpha[c]);
         xnew[i] = xn;
+        if (xfinal != nullptr) xfinal[i] = unscale(xn, sdiv[c]);
         if (need_prev) {
             const T d = sub(xn, xprev[i]);
             if (vnext != nullptr) vnext[i] = add(xn, scale(d, coef));
@@ -192,7 +202,8 @@ struct EpiProxStepH {
     static constexpr bool kVec4 = std::is_same<T, float>::value;
     bool vec_ok() const {
         return al16_ptr(rs) && al16_ptr(xprev) && al16_ptr(xnew) && al16_ptr(alpha) && al16_ptr(tolk) &&
-               (vnext == nullptr || al16_ptr(vnext)) && (ld % 4) == 0;
+               (vnext == nullptr || al16_ptr(vnext)) && (xfinal == nullptr || (al16_ptr(xfinal) && al16_ptr(sdiv))) &&
+               (ld % 4) == 0;
     }
     __device__ __forceinline__ void vec4(int r, int c0, f32x4 back, int) const {
         if constexpr (std::is_same<T, float>::value) {
@@ -204,6 +215,13 @@ struct EpiProxStepH {
 #pragma unroll
             for (int e = 0; e < 4; ++e) xn[e] = prox_apply<PROX>(back[e] + r4[e], li * a4[e]);
             *reinterpret_cast<f32x4*>(xnew + i) = xn;
+            if (xfinal != nullptr) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sdiv + c0);
+                f32x4 xf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xf[e] = xn[e] / s4[e];
+                *reinterpret_cast<f32x4*>(xfinal + i) = xf;
+            }
             if (need_prev) {
                 const f32x4 p4 = *reinterpret_cast<const f32x4*>(xprev + i);
                 f32x4 vn;
@@ -222,7 +240,7 @@ struct EpiProxStepH {
     static constexpr bool kCVec2 = std::is_same<T, c64>::value;
     bool cvec_ok() const {
         return al16_ptr(rs) && al16_ptr(xprev) && al16_ptr(xnew) && (vnext == nullptr || al16_ptr(vnext)) &&
-               (ld % 2) == 0;
+               (xfinal == nullptr || al16_ptr(xfinal)) && (ld % 2) == 0;
     }
     __device__ __forceinline__ void cvec2(int r, int c0, f32x4 back, int) const {
         if constexpr (std::is_same<T, c64>::value) {
@@ -238,6 +256,10 @@ struct EpiProxStepH {
                 xn4[2 * e] = xn[e].re; xn4[2 * e + 1] = xn[e].im;
             }
             *reinterpret_cast<f32x4*>(xnew + i) = xn4;
+            if (xfinal != nullptr) {
+                const float s0 = sdiv[c0], s1 = sdiv[c0 + 1];
+                *reinterpret_cast<f32x4*>(xfinal + i) = f32x4{xn4[0] / s0, xn4[1] / s0, xn4[2] / s1, xn4[3] / s1};
+            }
             if (need_prev) {
                 const f32x4 p4 = *reinterpret_cast<const f32x4*>(xprev + i);
                 f32x4 vn4;
@@ -256,10 +278,13 @@ struct EpiProxStepH {
     }
 };
 
-// AAt <- I - Linv AAt (in place, [K, K]) and yAt <- Linv yAt (in place, [N, K]): the H form's two operands
+// AAt <- I - Linv AAt (in place, [K, K]), yAt <- Linv yAt (in place, [N, K]): the H form's two operands; and, in the
+// same pass over [N, K], the solver's starting point xs = x * s (lasso.py:131; xsrc null: already done)
 template <class T>
 __global__ void __launch_bounds__(256) hform_prepare_kernel(T* __restrict__ AAt, long K, T* __restrict__ yAt,
-                                                            long nk, const real_t<T>* __restrict__ Linv) {
+                                                            long nk, const real_t<T>* __restrict__ Linv,
+                                                            const T* __restrict__ xsrc,
+                                                            const real_t<T>* __restrict__ s, T* __restrict__ xs) {
     typedef real_t<T> R;
     const R li = Linv[0];
     const long kk = K * K;
@@ -270,7 +295,9 @@ __global__ void __launch_bounds__(256) hform_prepare_kernel(T* __restrict__ AAt,
             if (r == c) h = add(h, from_real<T>(R(1)));
             AAt[i] = h;
         } else {
-            yAt[i - kk] = scale(yAt[i - kk], li);
+            const long j = i - kk;
+            yAt[j] = scale(yAt[j], li);
+            if (xsrc != nullptr) xs[j] = scale(xsrc[j], s[j % K]);
         }
     }
 }
@@ -802,6 +829,9 @@ inline int gram_kk(dcp_handle* h, const T* P, const T* Q, int K, int F, LassoWs<
     g.A = P; g.lda = F; g.B = Q; g.ldb = F; g.M = K; g.N = K; g.K = F;
     g.conjB = true;
     g.ext_ws = w.ext1;
+    // float32, >= 256 atoms: 64 x 64 tiles x 8 splits (tools/gemm_hook_sweep.py 0 512 512 4096: 31 us with the
+    // slab sum against 45 us for the 128 x 128 x 64 tile x 32 splits the automatic plan takes)
+    if (std::is_same<T, float>::value && K >= 256 && K <= 1024) g.tile = TILE_SMALL;
     plan_splits<FORM_NT>(g, 512, kMaxSplits);
     if ((size_t)g.ksplits * K * K > w.slab_count) return fail(h, DCP_ERR_INTERNAL, "lasso slab plan");
     DCP_LAUNCH_OK(h, (gemm<FORM_NT>(h->stream, g, EpiSlab<T>{w.slabs, K, (long)K * K})));
@@ -904,9 +934,14 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
                        mask_ndim == 2 ? R(1) : R(F), w.alphak, w.tolk);
     DCP_LAUNCH_OK(h, hipGetLastError());
     T* xcur = w.xb[0];
-    hipLaunchKernelGGL((col_scale_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st, (const T*)X,
-                       (const R*)w.s, (long)N, (long)K, 1, xcur);
-    DCP_LAUNCH_OK(h, hipGetLastError());
+    // ista / acc_ista / fista without a 2-D mask: x * s is formed by hform_prepare_kernel in its pass over [N, K]
+    const bool hform_family = (method == DCP_LASSO_ISTA || method == DCP_LASSO_ACC_ISTA || method == DCP_LASSO_FISTA) &&
+                              mask_ndim != 2;
+    if (!hform_family) {
+        hipLaunchKernelGGL((col_scale_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st, (const T*)X,
+                           (const R*)w.s, (long)N, (long)K, 1, xcur);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+    }
 
     // ---- yAt = (y o M) An^H ----
     {
@@ -929,6 +964,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
     const R* rowscale = mask_ndim == 2 ? w.rowscale : nullptr;
     int it = maxiter - 1;
     T* result = xcur;
+    bool final_in_place = false;   // the last iteration's epilogue already wrote result / s into X
 
     // ---- parallel_cd: p = int(K / Gershgorin(A A^H)), unmasked Gram matrix in every variant
     //      (lasso.py:464-470, 503-509); p <= 1 falls back to plain coordinate descent ----
@@ -1191,7 +1227,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         const bool hform = (mask_ndim != 2);
         if (hform) {
             hipLaunchKernelGGL((hform_prepare_kernel<T>), dim3(grid_for((long)K * K + (long)N * K)), dim3(256), 0, st,
-                               w.AAt, (long)K, w.yAt, (long)N * K, (const R*)w.scal);
+                               w.AAt, (long)K, w.yAt, (long)N * K, (const R*)w.scal, (const T*)X, (const R*)w.s, xcur);
             DCP_LAUNCH_OK(h, hipGetLastError());
         }
 
@@ -1206,6 +1242,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         T* lastNw = xcur;
         double beta = 1.0;
         bool converged = false;
+        bool wrote_final = false;
         // The stop test of a check iteration (i % 10 == 0, lasso.py:293) is read ONE iteration late: its flag
         // travels to the host behind an event while iteration i + 1 is already enqueued, so the GPU does not
         // idle through a host round trip in the middle of every solve (the dictionary step runs ten
@@ -1286,6 +1323,11 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
                     a.tile = TILE_MID;
                 EpiProxStepH<T, PROX> epih{w.yAt, P, Nw, mom ? Vn : (T*)nullptr, (long)K, w.scal, w.alphak, w.tolk,
                                            coef, check, (check || mom) ? 1 : 0, w.flag};
+                if (i == maxiter - 1 && method != DCP_LASSO_ACC_ISTA) {   // the iterate lasso.py:297 / :415 return
+                    epih.xfinal = X;
+                    epih.sdiv = w.s;
+                    wrote_final = true;
+                }
                 DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, epih)));
             }
             if (had_pending) {   // the check iteration before this one: was its test met?  (lasso.py:293-294)
@@ -1313,12 +1355,15 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         // QUIRK: on exhaustion ista / fista return the latest iterate, acc_ista the one
         // before it (its `x0 = x0_new` sits at the top of the loop body, lasso.py:351-357).
         if (!converged) result = (method == DCP_LASSO_ACC_ISTA) ? lastP : lastNw;
+        final_in_place = wrote_final && !converged;
     }
 
     // ---- x / s  (lasso.py:189) ----
-    hipLaunchKernelGGL((col_scale_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st,
-                       (const T*)result, (const R*)w.s, (long)N, (long)K, 0, X);
-    DCP_LAUNCH_OK(h, hipGetLastError());
+    if (!final_in_place) {
+        hipLaunchKernelGGL((col_scale_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st,
+                           (const T*)result, (const R*)w.s, (long)N, (long)K, 0, X);
+        DCP_LAUNCH_OK(h, hipGetLastError());
+    }
     if (!extra.no_final_sync) DCP_HIP_OK(h, hipStreamSynchronize(st));
     *it_out = it;
     return DCP_OK;
