@@ -106,6 +106,26 @@ def host_cpu_info():
     return model, (len(cores) or len(affinity)), len(affinity)
 
 
+def cgroup_cpu_quota():
+    """CPUs this container may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.
+    Threads beyond it do not add throughput: the kernel throttles the whole group for the rest of the period
+    (the GPU boxes of this pool: 16 CPUs on a 256-thread host)."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            return float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+            return q / per
+    except Exception:
+        pass
+    return None
+
+
 def host_residual(y, x, d, block=8192):
     """||y - x d||_F with float64 accumulation, evaluated on the host in row blocks (the same
     function scores the GPU's and the oracle's iterates, so a difference can only come from x, D)."""
@@ -131,13 +151,15 @@ def parity_and_cpu_baseline(torch, lib, h, Y, D0, timed_iters=3):
     from decomp_amd import _arrays, _hip
     from oracle import nmf as onmf, common
     model, phys, logical = host_cpu_info()
-    threads, blas, limiter = phys, 'unknown', None
+    quota = cgroup_cpu_quota()
+    want = phys if quota is None else max(1, min(phys, int(quota)))     # no more BLAS threads than CPUs we may use
+    threads, blas, limiter = want, 'unknown', None
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
         pools = [p for p in threadpool_info() if p.get('user_api') == 'blas']
         if pools:
             blas = '%s %s' % (pools[0].get('internal_api'), pools[0].get('version'))
-        limiter = threadpool_limits(limits=phys, user_api='blas')
+        limiter = threadpool_limits(limits=want, user_api='blas')
         pools = [p for p in threadpool_info() if p.get('user_api') == 'blas']
         if pools:   # what the BLAS really runs with (a build-time thread cap may sit below `phys`)
             threads = int(max(p.get('num_threads', 1) for p in pools))
@@ -182,11 +204,13 @@ def parity_and_cpu_baseline(torch, lib, h, Y, D0, timed_iters=3):
               'pass': bool(max(rel) <= tol)}
     base = {'value': 1.0 / per_iter, 'unit': 'iterations/s', 'cores': threads, 'kind': 'port',
             'blas': blas, 'cpu_model': model, 'physical_cores': phys, 'affinity_cpus': logical,
+            'cgroup_cpu_quota': quota,
             's_per_iteration': per_iter,
             'sample': 'oracle.nmf.mu_step (NumPy/BLAS, reference 6-GEMM formulation) at the FULL '
                       '%dx%d k=%d fp32 shape on the GPU run\'s own Y: %d timed iterations after 1 '
-                      'warm-up (%.1f s), %d BLAS threads' % (n_rows, N_FEAT, N_ATOMS, len(times) - 1,
-                                                             sum(times), threads)}
+                      'warm-up (%.1f s), %d BLAS threads (physical cores %d, container CPU quota %s)'
+                      % (n_rows, N_FEAT, N_ATOMS, len(times) - 1, sum(times), threads, phys,
+                         'none' if quota is None else '%g CPUs' % quota)}
     return parity, base
 
 

@@ -37,11 +37,26 @@ def timed(fn, reps):
     return (time.perf_counter() - t0) / reps, out
 
 
+def _blas_threads_within_quota():
+    """Cap the host BLAS at the container's CPU quota (threads beyond it get the whole group throttled)."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q == 'max':
+            return None, None
+        n = max(1, int(float(q) / float(per)))
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=n, user_api='blas'), n
+    except Exception:
+        return None, None
+
+
 def run(with_cpu=True, cpu_budget_s=20.0):
     import torch
     import decomp_amd
     from oracle import nmf as onmf, lasso as olasso
-    res = {'nmf_mu_F500_N2000_K10_100it': {}, 'lasso_1100x100_A90x100_5alphas': {}}
+    limiter, nthreads = _blas_threads_within_quota()
+    res = {'nmf_mu_F500_N2000_K10_100it': {}, 'lasso_1100x100_A90x100_5alphas': {},
+           'cpu_blas_threads': nthreads if nthreads is not None else 'library default'}
     y, D, mask = nmf_data()
     yd, Dd, md = (torch.from_numpy(a).cuda() for a in (y, D, mask))
     for tag, m_np, m_dev in (('nomask', None, None), ('mask', mask, md)):
@@ -79,6 +94,8 @@ def run(with_cpu=True, cpu_budget_s=20.0):
             spent += sc
             e.update({'cpu_ms_per_call': round(1e3 * sc, 2), 'it_cpu': itc, 'gpu_speedup': round(sc / s, 2)})
         res['lasso_1100x100_A90x100_5alphas'][method] = e
+    if limiter is not None:
+        limiter.restore_original_limits()
     return res
 
 
