@@ -90,8 +90,10 @@ struct AtomFusedArgsC {
     const c64* Dold;      // D_new rows of the next block (not yet updated) [32, F]
     const c64* rden;      // [32] of the next block
     float* Pnext;         // planar [64, F]
+    float* Pnext2;        // ksplit == 2: the second half of the reduction lands here as -acc * rden (summed by the apply kernel)
     int K2, F;            // K2 = 2 K
     int has_next;
+    int ksplit;           // 1 or 2 workgroups per column tile (the 2K-deep product on 2 F/64 CUs instead of F/64)
 };
 
 template <class T = c64>
@@ -110,14 +112,20 @@ __global__ void __launch_bounds__(256) atom_recur_lookahead_c64_kernel(AtomFused
     float* sB0 = smem + 2 * GA::ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-    const int n0 = (blockIdx.x - 1) * 64;
-    const int nkb = a.K2 / 64;
+    const int ntile = a.F / 64;
+    const int wg = blockIdx.x - 1;
+    const int kh = wg / ntile;                       // which half of the reduction (ksplit == 2)
+    const int n0 = (wg - kh * ntile) * 64;
+    const int nkb_all = a.K2 / 64;
+    const int kb0 = kh * (nkb_all / a.ksplit);
+    const int nkb = (a.ksplit == 2) ? nkb_all / 2 : nkb_all;
+    const int k00 = kb0 * 64;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     f32x4 ra[GA::F4], rb[GB::F4];
-    panel_gload<KMAJOR, 64, 64, false, 256>(ra, a.Alook, (long)a.K2, 0, 64, 0, a.K2, tid);
-    panel_gload<XMAJOR, 64, 64, false, 256>(rb, a.Dhat, (long)a.F, n0, a.F, 0, a.K2, tid);
+    panel_gload<KMAJOR, 64, 64, false, 256>(ra, a.Alook, (long)a.K2, 0, 64, k00, a.K2, tid);
+    panel_gload<XMAJOR, 64, 64, false, 256>(rb, a.Dhat, (long)a.F, n0, a.F, k00, a.K2, tid);
     panel_lds_store<KMAJOR, 64, 64, 256>(sA0, ra, tid);
     panel_lds_store<XMAJOR, 64, 64, 256>(sB0, rb, tid);
     __syncthreads();
@@ -125,8 +133,8 @@ __global__ void __launch_bounds__(256) atom_recur_lookahead_c64_kernel(AtomFused
         const int cur = kb & 1;
         const bool more = (kb + 1) < nkb;
         if (more) {
-            panel_gload<KMAJOR, 64, 64, false, 256>(ra, a.Alook, (long)a.K2, 0, 64, (kb + 1) * 64, a.K2, tid);
-            panel_gload<XMAJOR, 64, 64, false, 256>(rb, a.Dhat, (long)a.F, n0, a.F, (kb + 1) * 64, a.K2, tid);
+            panel_gload<KMAJOR, 64, 64, false, 256>(ra, a.Alook, (long)a.K2, 0, 64, k00 + (kb + 1) * 64, a.K2, tid);
+            panel_gload<XMAJOR, 64, 64, false, 256>(rb, a.Dhat, (long)a.F, n0, a.F, k00 + (kb + 1) * 64, a.K2, tid);
         }
         mma_64x64x64<KMAJOR, XMAJOR>(acc, sA0 + cur * GA::ELEMS, sB0 + cur * GB::ELEMS, wm, wn, l31, h);
         if (more) {
@@ -143,9 +151,15 @@ __global__ void __launch_bounds__(256) atom_recur_lookahead_c64_kernel(AtomFused
         const int m = row >> 1;
         const long i = (long)m * a.F + col;
         const c64 v{acc[r], acc[r + 1]};
-        const c64 p = add(mul(sub(a.Bn[i], v), a.rden[m]), a.Dold[i]);
-        a.Pnext[(long)row * a.F + col] = p.re;
-        a.Pnext[(long)(row + 1) * a.F + col] = p.im;
+        if (kh == 0) {
+            const c64 p = add(mul(sub(a.Bn[i], v), a.rden[m]), a.Dold[i]);
+            a.Pnext[(long)row * a.F + col] = p.re;
+            a.Pnext[(long)(row + 1) * a.F + col] = p.im;
+        } else {        // the other half of the sum: (B - v1 - v2) rden + Dold = [(B - v1) rden + Dold] + (-v2 rden)
+            const c64 p = mul(c64{-v.re, -v.im}, a.rden[m]);
+            a.Pnext2[(long)row * a.F + col] = p.re;
+            a.Pnext2[(long)(row + 1) * a.F + col] = p.im;
+        }
     }
 }
 
@@ -156,6 +170,7 @@ struct AtomApplyArgsC {
     float* Dhat_blk;      // planar rows of this block in the [2K, F] image (output)
     const float* Aprev;   // [64, 64]  extended -rden * A[next block, this block]   (has_next)
     float* Pnext;         // planar [64, F]   in: look-ahead part, out: complete P of the next block
+    const float* Pnext2;  // nullable: the second half of a split look-ahead product (added in)
     float* slabs;         // [F / 64][64 * 64]  real Gram slabs of the next block
     int F;
     int has_next;
@@ -210,7 +225,9 @@ __global__ void __launch_bounds__(256) atom_apply_c64_kernel(AtomApplyArgsC a) {
     for (int r = 0; r < 16; ++r) {
         const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const long i = (long)row * a.F + n0 + cl;
-        const float pn = a.Pnext[i] + acc[r];
+        float pn = a.Pnext[i];
+        if (a.Pnext2 != nullptr) pn += a.Pnext2[i];
+        pn += acc[r];
         a.Pnext[i] = pn;
         sT[GK::kchunk(row, cl >> 2) + (cl & 3)] = pn;     // element (row, k = column)
     }
@@ -245,6 +262,7 @@ inline int atom_sweep_fused_c64(dcp_handle* h, const c64* A, const c64* B, c64* 
     float* E_ext = Aprev_ext + (size_t)2 * K * 64;
     float* slabs = reinterpret_cast<float*>(w.slabs);            // 2 x slab_count floats
     float* Phat = reinterpret_cast<float*>(w.P);                 // 2 x [64, F] floats inside the complex buffer
+    float* P2 = Phat + (size_t)2 * 64 * F;                       // a third [64, F]: second half of a split look-ahead
     if ((size_t)ntile * 64 * 64 > 2 * w.slab_count) return fail(h, DCP_ERR_INTERNAL, "atom slab plan");
     hipLaunchKernelGGL((atom_prep_kernel<c64>), dim3(grid_for((long)K * K, 256)), dim3(256), 0, st, 32, K, A,
                        w.Ablk, w.Wl, w.rden, w.Alook, w.Aprev, (float*)nullptr, (float*)nullptr, (float*)nullptr);
@@ -275,7 +293,7 @@ inline int atom_sweep_fused_c64(dcp_handle* h, const c64* A, const c64* B, c64* 
         AtomFusedArgsC fa;
         fa.G = nullptr; fa.Wl = nullptr; fa.E = nullptr; fa.E_ext = nullptr;
         fa.Alook = Ablk0_ext; fa.Dhat = Dhat; fa.Bn = B; fa.Dold = Dnew; fa.rden = w.rden;
-        fa.Pnext = Phat; fa.K2 = 2 * K; fa.F = F; fa.has_next = 1;
+        fa.Pnext = Phat; fa.Pnext2 = nullptr; fa.K2 = 2 * K; fa.F = F; fa.has_next = 1; fa.ksplit = 1;
         hipLaunchKernelGGL(atom_recur_lookahead_c64_kernel<c64>, dim3(1 + ntile), dim3(256), kLds, st, fa);
         DCP_LAUNCH_OK(h, hipGetLastError());
         GemmArgs<float> g;
@@ -300,13 +318,18 @@ inline int atom_sweep_fused_c64(dcp_handle* h, const c64* A, const c64* B, c64* 
         fa.Bn = has_next ? B + (long)k1 * F : nullptr;
         fa.Dold = has_next ? Dnew + (long)k1 * F : nullptr;
         fa.rden = has_next ? w.rden + k1 : nullptr;
-        fa.Pnext = Pnext; fa.K2 = 2 * K; fa.F = F; fa.has_next = has_next ? 1 : 0;
-        hipLaunchKernelGGL(atom_recur_lookahead_c64_kernel<c64>, dim3(has_next ? 1 + ntile : 1), dim3(256), kLds, st, fa);
+        // the 2K-deep look-ahead product in two halves when that still fits one round of CUs: the launch is as long
+        // as its slower part, and with F / 64 workgroups of 16 K blocks that was the product, not the recursion
+        const int ksplit = (((2 * K) / 64) % 2 == 0 && 2 * ntile <= 256) ? 2 : 1;
+        fa.Pnext = Pnext; fa.Pnext2 = P2; fa.K2 = 2 * K; fa.F = F; fa.has_next = has_next ? 1 : 0; fa.ksplit = ksplit;
+        hipLaunchKernelGGL(atom_recur_lookahead_c64_kernel<c64>, dim3(has_next ? 1 + ksplit * ntile : 1), dim3(256), kLds,
+                           st, fa);
         DCP_LAUNCH_OK(h, hipGetLastError());
         AtomApplyArgsC aa;
         aa.E_ext = E_ext; aa.P = P; aa.Dblk = Dnew + (long)k0 * F; aa.Dhat_blk = Dhat + (size_t)(2 * k0) * F;
         aa.Aprev = has_next ? Aprev_ext + (size_t)(2 * k1) * 64 : nullptr;
-        aa.Pnext = Pnext; aa.slabs = slabs; aa.F = F; aa.has_next = has_next ? 1 : 0;
+        aa.Pnext = Pnext; aa.Pnext2 = (has_next && ksplit == 2) ? P2 : nullptr;
+        aa.slabs = slabs; aa.F = F; aa.has_next = has_next ? 1 : 0;
         hipLaunchKernelGGL(atom_apply_c64_kernel<c64>, dim3(ntile), dim3(256), 0, st, aa);
         DCP_LAUNCH_OK(h, hipGetLastError());
         if (has_next) {

@@ -192,15 +192,32 @@ __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int
     const int tid = threadIdx.x, i = tid & 63, w = tid >> 6;
     const bool lane_ok = i < BMAX;
     const bool live = i < nb;
-    for (int e = tid; e < nb * BMAX; e += 256) sW[e / BMAX][e % BMAX] = Wl[(e / BMAX) * kAtomBlkMax + (e % BMAX)];
-    for (int e = tid; e < nb * nb; e += 256) {          // coalesced read of G; sM[k][i] = G[i][k]
-        const int r = e / nb, cc = e % nb;
-        sM[cc][r] = widen(G[e]);
-    }
-    for (int e = tid; e < nb * BMAX; e += 256) {
-        const int k = e / BMAX, ii = e % BMAX;
-        sE[k][ii] = (ii == k) ? from_real<WT>(WR(1)) : zero_of<WT>();
-        if (ii >= nb) sM[k][ii] = zero_of<WT>();
+    // Every global load of the prologue is issued before the first LDS store (one element per loop trip is a chain of
+    // 16 memory round trips: 6.9 of the kernel's 25 us, in-kernel stamps).  sM[k][i] = G[i][k] = conj(G[k][i]): G = P P^H
+    // is Hermitian bit for bit (same products, same summation order on both sides of the diagonal), so the image is
+    // filled row by row -- the transposed fill wrote 64 lanes into one LDS bank.
+    {
+        constexpr int U = (BMAX * BMAX + 255) / 256;
+        T gv[U], wl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = tid + 256 * u;
+            const int k = e / BMAX, ii = e % BMAX;
+            const bool in = (k < nb && ii < nb);
+            gv[u] = G[in ? k * nb + ii : 0];
+            wl[u] = Wl[(k < nb ? k : 0) * kAtomBlkMax + ii];
+            if (!in) gv[u] = zero_of<T>();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = tid + 256 * u;
+            const int k = e / BMAX, ii = e % BMAX;
+            if (k < nb) {
+                sW[k][ii] = wl[u];
+                sM[k][ii] = conj_of(widen(gv[u]));
+                sE[k][ii] = (ii == k) ? from_real<WT>(WR(1)) : zero_of<WT>();
+            }
+        }
     }
     __syncthreads();
     for (int s0 = 0; s0 < nb; s0 += kAtomSub) {
@@ -264,16 +281,23 @@ __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int
         }
         __syncthreads();
         // ---- every later row loses this sub-block's contribution (rows are independent) ----
-        if (lane_ok) {
+        if (lane_ok && s1 + w < nb) {
+            // the sub-block's finished rows are the same for every later row: fetched once per wave (the compiler
+            // cannot hoist them itself across the stores to sE / sM below)
+            WT ej[kAtomSub], mj[kAtomSub];
+#pragma unroll
+            for (int t = 0; t < kAtomSub; ++t) {             // s1 - s0 == kAtomSub here (k >= s1 exists only then)
+                ej[t] = sE[s0 + t][i];
+                mj[t] = sM[s0 + t][i];
+            }
             for (int k = s1 + w; k < nb; k += 4) {
                 WT c = sE[k][i], y = sM[k][i];
                 WT c1 = zero_of<WT>(), y1 = zero_of<WT>();
 #pragma unroll
                 for (int t = 0; t < kAtomSub; t += 2) {
-                    const int j0 = s0 + t, j1 = s0 + t + 1;     // s1 - s0 == kAtomSub here (k >= s1 exists only then)
-                    const WT w0 = widen(sW[k][j0]), w1 = widen(sW[k][j1]);
-                    c = msub(c, w0, sE[j0][i]);            c1 = msub(c1, w1, sE[j1][i]);
-                    y = msub(y, conj_of(w0), sM[j0][i]);   y1 = msub(y1, conj_of(w1), sM[j1][i]);
+                    const WT w0 = widen(sW[k][s0 + t]), w1 = widen(sW[k][s0 + t + 1]);
+                    c = msub(c, w0, ej[t]);            c1 = msub(c1, w1, ej[t + 1]);
+                    y = msub(y, conj_of(w0), mj[t]);   y1 = msub(y1, conj_of(w1), mj[t + 1]);
                 }
                 sE[k][i] = add(c, c1);
                 sM[k][i] = add(y, y1);
