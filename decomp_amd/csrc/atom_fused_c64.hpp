@@ -97,13 +97,14 @@ struct AtomFusedArgsC {
 };
 
 template <class T = c64>
-__global__ void __launch_bounds__(256) atom_recur_lookahead_c64_kernel(AtomFusedArgsC a) {
+__global__ void __launch_bounds__(kAtomRecurThreads) atom_recur_lookahead_c64_kernel(AtomFusedArgsC a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
     if (blockIdx.x == 0) {
-        if (a.G != nullptr) atom_recur_body<c64>(fused_lds, 32, a.G, a.Wl, a.E, (float*)nullptr, a.E_ext);
+        if (a.G != nullptr)
+            atom_recur_body<c64, kAtomRecurThreads>(fused_lds, 32, a.G, a.Wl, a.E, (float*)nullptr, a.E_ext);
         return;
     }
-    if (!a.has_next) return;
+    if (!a.has_next || threadIdx.x >= 256) return;
     // ---- planar P_next[:, tile] = (Bn - Alook . Dcur) * rden + Dold      (EpiAtomP of the generic path) ----
     typedef PanelGeom<KMAJOR, 64, 64, 256> GA;   // extended Alook rows: [64][64 k]
     typedef PanelGeom<XMAJOR, 64, 64, 256> GB;   // planar Dcur rows:    [64 k][64 cols]
@@ -294,7 +295,7 @@ inline int atom_sweep_fused_c64(dcp_handle* h, const c64* A, const c64* B, c64* 
         fa.G = nullptr; fa.Wl = nullptr; fa.E = nullptr; fa.E_ext = nullptr;
         fa.Alook = Ablk0_ext; fa.Dhat = Dhat; fa.Bn = B; fa.Dold = Dnew; fa.rden = w.rden;
         fa.Pnext = Phat; fa.Pnext2 = nullptr; fa.K2 = 2 * K; fa.F = F; fa.has_next = 1; fa.ksplit = 1;
-        hipLaunchKernelGGL(atom_recur_lookahead_c64_kernel<c64>, dim3(1 + ntile), dim3(256), kLds, st, fa);
+        hipLaunchKernelGGL(atom_recur_lookahead_c64_kernel<c64>, dim3(1 + ntile), dim3(kAtomRecurThreads), kLds, st, fa);
         DCP_LAUNCH_OK(h, hipGetLastError());
         GemmArgs<float> g;
         g.A = Phat; g.lda = F; g.B = Phat; g.ldb = F; g.M = 64; g.N = 64; g.K = F;
@@ -322,7 +323,7 @@ inline int atom_sweep_fused_c64(dcp_handle* h, const c64* A, const c64* B, c64* 
         // as its slower part, and with F / 64 workgroups of 16 K blocks that was the product, not the recursion
         const int ksplit = (((2 * K) / 64) % 2 == 0 && 2 * ntile <= 256) ? 2 : 1;
         fa.Pnext = Pnext; fa.Pnext2 = P2; fa.K2 = 2 * K; fa.F = F; fa.has_next = has_next ? 1 : 0; fa.ksplit = ksplit;
-        hipLaunchKernelGGL(atom_recur_lookahead_c64_kernel<c64>, dim3(has_next ? 1 + ksplit * ntile : 1), dim3(256), kLds,
+        hipLaunchKernelGGL(atom_recur_lookahead_c64_kernel<c64>, dim3(has_next ? 1 + ksplit * ntile : 1), dim3(kAtomRecurThreads), kLds,
                            st, fa);
         DCP_LAUNCH_OK(h, hipGetLastError());
         AtomApplyArgsC aa;

@@ -175,7 +175,7 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 // LDS-fed terms; two barriers per 8 atoms instead of two per atom.  G (b x b, leading dim nb), Wl (leading dim kAtomBlkMax) -> E (leading dim nb).
 constexpr int kAtomSub = 8;
 
-template <class T>
+template <class T, int NTH = 256>
 __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int nb, const T* __restrict__ G,
                                                 const T* __restrict__ Wl, T* __restrict__ E,
                                                 real_t<T>* __restrict__ E_rows = nullptr,
@@ -197,11 +197,11 @@ __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int
     // is Hermitian bit for bit (same products, same summation order on both sides of the diagonal), so the image is
     // filled row by row -- the transposed fill wrote 64 lanes into one LDS bank.
     {
-        constexpr int U = (BMAX * BMAX + 255) / 256;
+        constexpr int U = (BMAX * BMAX + NTH - 1) / NTH;
         T gv[U], wl[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int e = tid + 256 * u;
+            const int e = tid + NTH * u;
             const int k = e / BMAX, ii = e % BMAX;
             const bool in = (k < nb && ii < nb);
             gv[u] = G[in ? k * nb + ii : 0];
@@ -210,7 +210,7 @@ __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int e = tid + 256 * u;
+            const int e = tid + NTH * u;
             const int k = e / BMAX, ii = e % BMAX;
             if (k < nb) {
                 sW[k][ii] = wl[u];
@@ -290,7 +290,7 @@ __device__ __forceinline__ void atom_recur_body(unsigned char* atom_lds_raw, int
                 ej[t] = sE[s0 + t][i];
                 mj[t] = sM[s0 + t][i];
             }
-            for (int k = s1 + w; k < nb; k += 4) {
+            for (int k = s1 + w; k < nb; k += NTH / 64) {     // (NTH / 64 waves share the later rows)
                 WT c = sE[k][i], y = sM[k][i];
                 WT c1 = zero_of<WT>(), y1 = zero_of<WT>();
 #pragma unroll
