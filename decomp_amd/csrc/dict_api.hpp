@@ -181,9 +181,9 @@ inline int dict_step_core(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, 
     DCP_TRY(dict_stats_core<T>(h, Y, X, D, Nb, F, K, alpha, lasso_method, lasso_iter, lasso_tol, (T*)nullptr,
                                lasso_it, lw, dw, /*keep_slabs=*/true));
     // a registered prefetch (dcp_dict_prefetch_rows_bytes: the NEXT minibatch's rows into the OTHER staging block)
-    // runs on the side stream beside the atom sweep, where the chip and its HBM are nearly idle (beside the LASSO's
-    // iterations it measured 1 % slower, LassoExtra::start_prefetch); joined before the step's last kernel.
-    DCP_TRY(start_registered_prefetch(h));
+    // is started by dict_update in front of the atom sweep and runs on the side stream beside it, where the chip and
+    // its HBM are nearly idle (beside the LASSO's iterations it measured 1 % slower, LassoExtra::start_prefetch);
+    // joined before the step's last kernel.
     R* md = maxdiff_dev ? maxdiff_dev : dw.scal;
     DCP_TRY(dict_update<T>(h, dw.slabs, (R)beta, A, B, D, Dnew, F, K, md, dw, dw.stat_nslabs));
     if (h->pf_inflight) {

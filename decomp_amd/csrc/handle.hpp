@@ -137,6 +137,16 @@ inline int main_after_side(dcp_handle* h) {
 int move_rows_on(dcp_handle* h, hipStream_t stream, const void* in, const int64_t* in_index, void* out,
                  const int64_t* out_index, int64_t rows, int64_t row_bytes);
 
+// Starts the handle's registered row gather on the side stream, ordered after what is on the main stream now.
+inline int start_registered_prefetch(dcp_handle* h) {
+    if (h->pf_rows <= 0 || h->pf_row_bytes <= 0) return DCP_OK;
+    DCP_TRY(side_after_main(h));
+    DCP_TRY(move_rows_on(h, h->side, h->pf_in, h->pf_index, h->pf_out, nullptr, h->pf_rows, h->pf_row_bytes));
+    h->pf_rows = 0;
+    h->pf_inflight = true;
+    return DCP_OK;
+}
+
 inline void ws_reset(dcp_handle* h) {
     h->arena_used = 0;
 }

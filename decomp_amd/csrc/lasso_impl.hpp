@@ -878,16 +878,6 @@ struct LassoExtra {
     bool start_prefetch = false;
 };
 
-// Starts the handle's registered row gather on the side stream, ordered after what is on the main stream now.
-inline int start_registered_prefetch(dcp_handle* h) {
-    if (h->pf_rows <= 0 || h->pf_row_bytes <= 0) return DCP_OK;
-    DCP_TRY(side_after_main(h));
-    DCP_TRY(move_rows_on(h, h->side, h->pf_in, h->pf_index, h->pf_out, nullptr, h->pf_rows, h->pf_row_bytes));
-    h->pf_rows = 0;
-    h->pf_inflight = true;
-    return DCP_OK;
-}
-
 // solve_fastpath (lasso.py:97-189).  Y [N,F], A [K,F], X [N,K] (in: initial estimate, out:
 // solution), mask: null, [F] (mask_ndim 1) or [N,F] (mask_ndim 2).  *it_out as the reference.
 template <class T, int PROX>

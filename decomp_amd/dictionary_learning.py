@@ -140,7 +140,6 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
     n_loop = int(N / minibatch)                                          # utils/data.py:107-108
     y_stage = [torch.empty((minibatch, F), dtype=y.dtype, device=dev) for _ in range(2)]
     x_stage = torch.empty((minibatch, K), dtype=x.dtype, device=dev)
-    md_dev = torch.zeros((2,), dtype=rdt, device=dev)
     md_host = _pinned(torch, 'md', (2,), rdt)
     # two preallocated pinned blocks for the epochs' row orders, filled by a plain single-threaded copy
     # (Tensor.pin_memory() per epoch would run torch's parallel CPU copy: on a many-core host its worker
@@ -246,14 +245,15 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
             beta = (theta_plus1 - minibatch) / theta_plus1
             lib, h = _arrays.lib_handle(D)
             slot = count & 1
+            # max|D - D_new| is written by the step's last kernel straight into pinned host memory (device-mapped: the
+            # same pointer serves the GPU), no copy kernel behind the step
             rc = step(h, _arrays.ptr(y_stage[buf]), _arrays.ptr(x_stage), _arrays.ptr(D), _arrays.ptr(D_new),
                       _arrays.ptr(A), _arrays.ptr(B), minibatch, F, K, float(beta), float(alpha), code,
-                      int(lasso_iter), float(lasso_tol), _arrays.ptr(md_dev[slot:slot + 1]),
+                      int(lasso_iter), float(lasso_tol), _arrays.ptr(md_host[slot:slot + 1]),
                       ctypes.byref(lasso_it))
             _hip.check(h, rc, 'dcp_dict_step_async_' + sfx)
             t3 = _time.perf_counter()
             tacc['step_call'] += t3 - t2
-            md_host[slot:slot + 1].copy_(md_dev[slot:slot + 1], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(main)
             # stop test of the PREVIOUS step (:161-162), now that this one is enqueued
