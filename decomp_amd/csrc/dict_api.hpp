@@ -151,7 +151,12 @@ inline int dict_update_api(dcp_handle* h, const T* stats, double beta, T* A, T* 
         if (!dw.padA || !dw.padB || !dw.padD) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
     }
     if (!dw.partial) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
-    return dict_update<T>(h, stats, (R)beta, A, B, D, Dnew, F, K, maxdiff_dev, dw);
+    DCP_TRY(dict_update<T>(h, stats, (R)beta, A, B, D, Dnew, F, K, maxdiff_dev, dw));
+    if (h->pf_inflight) {     // a registered row prefetch was started beside the sweep: join it
+        DCP_TRY(main_after_side(h));
+        h->pf_inflight = false;
+    }
+    return DCP_OK;
 }
 
 // dictionary_learning.py:137-164 for one minibatch on one GPU; max|D - D_new| lands in the DEVICE scalar
