@@ -33,6 +33,13 @@ __device__ __forceinline__ void atomic_max_nonneg(float* p, float v) {
 __device__ __forceinline__ void atomic_max_nonneg(double* p, double v) {
     atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
 }
+// the value as the memory-side atomic unit holds it (a plain load may hit a line of this XCD's L2)
+__device__ __forceinline__ float atomic_read_nonneg(float* p) {
+    return __uint_as_float(atomicMax(reinterpret_cast<unsigned int*>(p), 0u));
+}
+__device__ __forceinline__ double atomic_read_nonneg(double* p) {
+    return __longlong_as_double((long long)atomicMax(reinterpret_cast<unsigned long long*>(p), 0ull));
+}
 
 // Block-wide reductions for 256-thread blocks; result valid in thread 0.
 template <class R>
@@ -255,7 +262,9 @@ __global__ void __launch_bounds__(256) row_normalize_kernel(const T* __restrict_
                                                             real_t<T>* __restrict__ rowmax,
                                                             real_t<T>* __restrict__ norm_out = nullptr,
                                                             real_t<T>* __restrict__ gmax = nullptr,
-                                                            real_t<T>* __restrict__ gmax_zero = nullptr) {
+                                                            real_t<T>* __restrict__ gmax_zero = nullptr,
+                                                            unsigned int* __restrict__ ticket = nullptr,
+                                                            real_t<T>* __restrict__ host_out = nullptr) {
     typedef real_t<T> R;
     __shared__ R sh[4];
     __shared__ R s_inv;
@@ -318,6 +327,17 @@ __global__ void __launch_bounds__(256) row_normalize_kernel(const T* __restrict_
             // *gmax must be zero on entry; the other slot is cleared for the next iteration.
             if (gmax != nullptr) atomic_max_nonneg(gmax, m);
             if (gmax_zero != nullptr && row == 0) *gmax_zero = R(0);
+            // The workgroup that arrives LAST (a ticket per row, no waiting) publishes the finished maximum to
+            // device-mapped pinned host memory: the host reads it behind the kernel's event, no copy kernel in
+            // between (4.2 us + a launch boundary per MU iteration).  *ticket must be zero on entry and is again on exit.
+            if (ticket != nullptr && gmax != nullptr) {
+                __threadfence();
+                if (atomicAdd(ticket, 1u) == gridDim.x - 1u) {
+                    *host_out = atomic_read_nonneg(gmax);
+                    __threadfence_system();
+                    atomicExch(ticket, 0u);
+                }
+            }
         }
     }
 }

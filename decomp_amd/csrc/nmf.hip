@@ -42,6 +42,7 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     plan.add<T>((size_t)K * F);   // second D buffer
     plan.add<T>((size_t)N * K);   // second x buffer
     plan.add<T>(2);               // max|dD| of the two iterations in flight
+    plan.add<unsigned int>(4);    // arrival ticket of the normalisation's workgroups
     const bool want_bits = masked && std::is_same<T, float>::value && lik == DCP_LIK_L2;
     if (want_bits) {
         plan.add<uint32_t>(mask_bits_words(N, F));
@@ -61,6 +62,7 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     T* D2 = ws_alloc<T>(h, (size_t)K * F);
     T* X2 = ws_alloc<T>(h, (size_t)N * K);
     T* maxdiff_dev = ws_alloc<T>(h, 2);
+    unsigned int* ticket = ws_alloc<unsigned int>(h, 4);
     uint32_t* mbits = nullptr;
     int* mflag = nullptr;
     if (want_bits) {
@@ -74,7 +76,7 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
         resid_tmp = gram ? ws_alloc<T>(h, (size_t)N * F) : ws.f;
         resid_part = ws_alloc<double>(h, resid_blocks);
     }
-    if (!stats || !D2 || !X2 || !maxdiff_dev || (want_resid && (!resid_tmp || !resid_part)))
+    if (!stats || !D2 || !X2 || !maxdiff_dev || !ticket || (want_resid && (!resid_tmp || !resid_part)))
         return fail(h, DCP_ERR_INTERNAL, "nmf workspace plan mismatch");
     void* hostv = nullptr;
     DCP_TRY(host_scratch(h, sizeof(double) * (resid_blocks + 4), &hostv));
@@ -96,6 +98,7 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
         if (binary) ws.mbits = mbits;
     }
     DCP_HIP_OK(h, hipMemsetAsync(maxdiff_dev, 0, 2 * sizeof(T), h->stream));
+    DCP_HIP_OK(h, hipMemsetAsync(ticket, 0, 4 * sizeof(unsigned int), h->stream));
 
     // Iteration `it` reads (x_{it-1}, D_{it-1}) from (Xc, Dc) and writes (x_it, D_it) to (Xn, Dn);
     // its max|dD| is copied to host slot it&1 behind an event.  The stop test of iteration it-1
@@ -115,10 +118,10 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
             DCP_TRY(comm_allreduce_sum(h, stats, (size_t)K * W,
                                        std::is_same<T, float>::value ? COMM_F32 : COMM_F64));
         }
+        // max|D - D_new| reaches the host without a copy kernel: the normalisation's last-arriving workgroup stores
+        // it into the pinned (device-mapped) slot, visible behind the event
         DCP_TRY(nmf_update<T>(h, stats, Dc, Dn, F, K, lik, masked, maxdiff_dev + slot, wu,
-                              maxdiff_dev + (slot ^ 1)));
-        DCP_HIP_OK(h, hipMemcpyAsync(host_md + slot, maxdiff_dev + slot, sizeof(T),
-                                     hipMemcpyDeviceToHost, h->stream));
+                              maxdiff_dev + (slot ^ 1), ticket, host_md + slot));
         DCP_HIP_OK(h, hipEventRecord(ev[slot], h->stream));
         if (want_resid) {   // parity/debug mode: synchronous
             DCP_TRY(nmf_residual<T>(h, Y, mask, Xn, Dn, N, F, K, resid_tmp, resid_part,

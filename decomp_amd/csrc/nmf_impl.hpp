@@ -411,7 +411,7 @@ inline int nmf_grad_x(dcp_handle* h, const T* Ypre, const T* mask, const T* X, c
 template <class T>
 inline int nmf_update(dcp_handle* h, const T* stats, const T* D, T* D_new, int64_t F64, int64_t K64,
                       int lik, bool masked, T* maxdiff_dev, NmfUpdateWs<T>& w,
-                      T* maxdiff_next = nullptr) {
+                      T* maxdiff_next = nullptr, unsigned int* ticket = nullptr, T* host_out = nullptr) {
     hipStream_t st = h->stream;
     const int F = (int)F64, K = (int)K64;
     const bool gram = (lik == DCP_LIK_L2 && !masked);
@@ -442,7 +442,7 @@ inline int nmf_update(dcp_handle* h, const T* stats, const T* D, T* D_new, int64
         // the max is formed with one atomic per row, and the other slot is cleared for the next
         hipLaunchKernelGGL((row_normalize_kernel<T>), dim3(K), dim3(256), 0, st, w.U, (long)F,
                            (long)F, 1, D, (long)F, D_new, (long)F, (T*)nullptr, (T*)nullptr,
-                           maxdiff_dev, maxdiff_next);
+                           maxdiff_dev, maxdiff_next, ticket, host_out);
         DCP_LAUNCH_OK(h, hipGetLastError());
         return DCP_OK;
     }
