@@ -400,3 +400,94 @@ def test_sharded_dictionary_early_exit_per_rank():
     x_all = np.concatenate([res[0][3], res[1][3]], axis=0)
     assert np.max(np.abs(x_all - x1)) <= 20 * lasso_tol                 # O(lasso_tol), codes are O(3)
     assert _err(res[0][2], D1) < 0.1
+
+
+def test_stop_test_fires_mid_epoch_speculative_step_is_discarded():
+    """Round 4: dictionary_learning.solve reads max|D - D_new| < tol (dictionary_learning.py:161-162) one step late and
+    drops the step it had enqueued speculatively (its codes are not scattered, its D_new is not returned).  A run whose
+    stop test fires in the MIDDLE of an epoch must return exactly what the oracle returns: same epoch number, the
+    dictionary of the converged step, and codes in the original row order with only the rows visited so far updated."""
+    from decomp_amd import dictionary_learning as dl
+    from oracle import dictionary_learning as odl
+    rng = np.random.RandomState(17)
+    N, F, K, mb = 203, 24, 5, 20
+    Dt = rng.randn(K, F)
+    xt = 2.0 * rng.randn(N, K) * (rng.uniform(size=(N, K)) < 0.4)
+    y = xt @ Dt + 0.05 * rng.randn(N, F)
+    D0 = Dt + 0.2 * rng.randn(K, F)
+    trace = []
+    odl.solve(y.copy(), D0.copy(), 0.02, tol=0.0, minibatch=mb, maxiter=4, lasso_method='ista', lasso_iter=12,
+              lasso_tol=1e-7, random_seed=5, trace=trace)
+    n_loop = N // mb
+    # a tolerance between the max|dD| of two consecutive steps in the middle of epoch 2
+    s = n_loop + 4
+    diffs = [t['maxdiff'] for t in trace]
+    first_below = None
+    for tol_step in range(s, len(diffs)):
+        cand = 0.5 * (diffs[tol_step] + min(diffs[:tol_step]))
+        if diffs[tol_step] < cand and all(d >= cand for d in diffs[:tol_step]) and tol_step % n_loop not in (0, n_loop - 1):
+            first_below = (tol_step, cand)
+            break
+    assert first_below is not None, diffs
+    step, tol = first_below
+    kw = dict(tol=tol, minibatch=mb, maxiter=4, lasso_method='ista', lasso_iter=12, lasso_tol=1e-7, random_seed=5)
+    ito, Do, xo = odl.solve(y.copy(), D0.copy(), 0.02, **kw)
+    it, D, x = dl.solve(y.copy(), D0.copy(), 0.02, **kw)
+    assert ito == step // n_loop + 1 and it == ito
+    assert _err(D, Do) < 1e-8 and _err(x, xo) < 1e-8
+    assert np.any(x == 1.0)            # rows not yet visited in the interrupted epoch (and the skipped tail) keep x = 1
+
+
+def test_async_step_and_registered_prefetch_equal_the_synchronous_step():
+    """dcp_dict_step_async_* (max|dD| left in caller memory, no host wait) with a row gather registered through
+    dcp_dict_prefetch_rows_bytes must leave x, D_new, A, B and max|dD| bit-identical to dcp_dict_step_*, and the
+    prefetched block must equal the plain gather."""
+    import ctypes
+    import torch
+    from decomp_amd import _arrays, _hip
+    g = torch.Generator(device='cuda')
+    g.manual_seed(3)
+    for dt, cplx in ((torch.float32, False), (torch.complex64, True)):
+        MB, F, K, N = 512, 256, 64, 2048
+
+        def randn(*sh):
+            r = torch.randn(sh, generator=g, device='cuda')
+            return torch.complex(r, torch.randn(sh, generator=g, device='cuda')) if cplx else r
+        Yall = randn(N, F)
+        D = randn(K, F)
+        _arrays.l2_normalize_(D, strict=True)
+        idx = torch.randperm(N, generator=g, device='cuda')[:MB].to(torch.int64)
+        idx_next = torch.randperm(N, generator=g, device='cuda')[:MB].to(torch.int64)
+        Y = Yall[idx].contiguous()
+        sfx = 'c64' if cplx else 'f32'
+        lib, h = _arrays.lib_handle(D)
+        outs = []
+        for mode in ('sync', 'async'):
+            x = torch.ones((MB, K), device='cuda', dtype=dt)
+            A = torch.zeros((K, K), device='cuda', dtype=dt)
+            B = torch.zeros((K, F), device='cuda', dtype=dt)
+            Dn = torch.empty_like(D)
+            lit = ctypes.c_int(0)
+            if mode == 'sync':
+                md = ctypes.c_double(0)
+                _hip.check(h, getattr(lib, 'dcp_dict_step_' + sfx)(
+                    h, _arrays.ptr(Y), _arrays.ptr(x), _arrays.ptr(D), _arrays.ptr(Dn), _arrays.ptr(A), _arrays.ptr(B),
+                    MB, F, K, (1.0 - MB) / 1.0, 0.02, _hip.LASSO_ISTA, 10, 1e-6, ctypes.byref(md), ctypes.byref(lit)), 'step')
+                mdv = md.value
+                staged = None
+            else:
+                md = torch.zeros((1,), device='cuda', dtype=torch.float32)
+                staged = torch.zeros((MB, F), device='cuda', dtype=dt)
+                _hip.check(h, lib.dcp_dict_prefetch_rows_bytes(h, _arrays.ptr(Yall), _arrays.ptr(idx_next), MB,
+                                                               F * Yall.element_size(), _arrays.ptr(staged)), 'prefetch')
+                _hip.check(h, getattr(lib, 'dcp_dict_step_async_' + sfx)(
+                    h, _arrays.ptr(Y), _arrays.ptr(x), _arrays.ptr(D), _arrays.ptr(Dn), _arrays.ptr(A), _arrays.ptr(B),
+                    MB, F, K, (1.0 - MB) / 1.0, 0.02, _hip.LASSO_ISTA, 10, 1e-6, _arrays.ptr(md), ctypes.byref(lit)), 'step_async')
+                torch.cuda.synchronize()
+                mdv = float(md.item())
+            outs.append((x, Dn, A, B, mdv, lit.value, staged))
+        a, b = outs
+        for i in range(4):
+            assert torch.equal(a[i], b[i]), (sfx, i)
+        assert a[5] == b[5] and abs(a[4] - b[4]) <= 1e-12 * max(1.0, abs(a[4]))
+        assert torch.equal(b[6], Yall[idx_next])
