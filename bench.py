@@ -581,8 +581,11 @@ def main():
     # does the Python loop over torch.distributed run instead; the JSON line says which (`config.loop`).
     sharded_run = world > 1 or args.force_sharded
     in_library = sharded_run and sharded.attach_communicator(D)
+    kind = sharded.communicator_kind(D) if in_library else None
     loop_name = ('single-GPU dcp_nmf_mu_f32' if not sharded_run else
-                 'in-library dcp_nmf_mu_sharded_f32 (ncclAllReduce on the solver stream)' if in_library else
+                 'in-library dcp_nmf_mu_sharded_f32 (ncclAllReduce on the solver stream)' if kind == 'rccl' else
+                 'in-library dcp_nmf_mu_sharded_f32, exchange through a host callback over torch.distributed (%s): '
+                 'a rehearsal, never a measurement' % backend if kind == 'external' else
                  'python sharded.mu_loop over torch.distributed (%s)' % backend)
 
     def barrier():

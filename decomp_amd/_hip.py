@@ -24,6 +24,8 @@ LASSO_POSITIVE = 0x100
 ERR_REF_TYPEERROR = -6
 ERR_COMM = -7
 COMM_ID_BYTES = 128
+# int fn(void* buf, int64 count, int dtype, void* hip_stream, void* user)  (dcp_comm_set_external)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 
 _c_int, _c_i64, _c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
 _c_f32, _c_f64 = ctypes.c_float, ctypes.c_double
@@ -40,6 +42,8 @@ SIGNATURES = {
     'dcp_comm_unique_id': (_c_int, [_c_vp, _c_i64]),
     'dcp_comm_init': (_c_int, [_c_vp, _c_vp, _c_int, _c_int]),
     'dcp_comm_destroy': (_c_int, [_c_vp]),
+    'dcp_comm_set_external': (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int]),
+    'dcp_memcpy': (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64]),
     'dcp_comm_info': (_c_int, [_c_vp, _P(_c_int), _P(_c_int)]),
     'dcp_comm_allreduce_sum_f32': (_c_int, [_c_vp, _c_vp, _c_i64]),
     'dcp_comm_allreduce_sum_f64': (_c_int, [_c_vp, _c_vp, _c_i64]),

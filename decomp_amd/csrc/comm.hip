@@ -80,6 +80,11 @@ int nccl_fail(dcp_handle* h, const char* what, ncclResult_t r) {
 namespace dcp {
 
 int comm_allreduce_sum(dcp_handle* h, void* buf, size_t count, int dtype) {
+    if (h->comm_ext != nullptr) {   // the caller's own exchange (dcp_comm_set_external)
+        const int rc = h->comm_ext(buf, (int64_t)count, dtype, reinterpret_cast<void*>(h->stream), h->comm_ext_user);
+        if (rc != 0) return fail(h, DCP_ERR_COMM, "external all-reduce callback failed: " + std::to_string(rc));
+        return DCP_OK;
+    }
     if (!h->comm) return fail(h, DCP_ERR_COMM, "the handle has no communicator (dcp_comm_init)");
     RcclApi& api = rccl();
     const ncclDataType_t dt = dtype == COMM_F64 ? ncclFloat64 : ncclFloat32;
@@ -89,7 +94,13 @@ int comm_allreduce_sum(dcp_handle* h, void* buf, size_t count, int dtype) {
 }
 
 void comm_release(dcp_handle* h) {
-    if (!h->comm) return;
+    h->comm_ext = nullptr;
+    h->comm_ext_user = nullptr;
+    if (!h->comm) {
+        h->comm_rank = 0;
+        h->comm_world = 1;
+        return;
+    }
     RcclApi& api = rccl();
     (void)hipStreamSynchronize(h->stream);
     if (api.ok) (void)api.CommDestroy(reinterpret_cast<ncclComm_t>(h->comm));
@@ -131,6 +142,26 @@ int dcp_comm_init(dcp_handle* h, const void* unique_id, int rank, int world) {
     return DCP_OK;
 }
 
+int dcp_comm_set_external(dcp_handle* h, dcp_allreduce_fn fn, void* user, int rank, int world) {
+    if (!h) return DCP_ERR_INVALID;
+    if (!fn || world < 1 || rank < 0 || rank >= world) return fail(h, DCP_ERR_INVALID, "bad callback / rank / world");
+    comm_release(h);
+    h->comm_ext = fn;
+    h->comm_ext_user = user;
+    h->comm_rank = rank;
+    h->comm_world = world;
+    return DCP_OK;
+}
+
+int dcp_memcpy(dcp_handle* h, void* dst, const void* src, int64_t bytes) {
+    if (!h) return DCP_ERR_INVALID;
+    if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(h, DCP_ERR_INVALID, "null pointer / negative size");
+    if (bytes == 0) return DCP_OK;
+    DCP_HIP_OK(h, hipSetDevice(h->device));
+    DCP_HIP_OK(h, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, h->stream));
+    return DCP_OK;
+}
+
 int dcp_comm_destroy(dcp_handle* h) {
     if (!h) return DCP_ERR_INVALID;
     comm_release(h);
@@ -139,8 +170,9 @@ int dcp_comm_destroy(dcp_handle* h) {
 
 int dcp_comm_info(dcp_handle* h, int* rank, int* world) {
     if (!h) return DCP_ERR_INVALID;
-    if (rank) *rank = h->comm ? h->comm_rank : 0;
-    if (world) *world = h->comm ? h->comm_world : 0;
+    const bool on = h->comm != nullptr || h->comm_ext != nullptr;
+    if (rank) *rank = on ? h->comm_rank : 0;
+    if (world) *world = on ? h->comm_world : 0;
     return DCP_OK;
 }
 

@@ -11,7 +11,7 @@ namespace dcp {
 
 enum { COMM_F32 = 0, COMM_F64 = 1 };
 
-inline bool comm_active(const dcp_handle* h) { return h->comm != nullptr; }
+inline bool comm_active(const dcp_handle* h) { return h->comm != nullptr || h->comm_ext != nullptr; }
 
 // In-place sum over the ranks of the handle's communicator, enqueued on h->stream (no host wait).
 int comm_allreduce_sum(dcp_handle* h, void* buf, size_t count, int dtype);

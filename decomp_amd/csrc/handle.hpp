@@ -39,6 +39,9 @@ struct dcp_handle {
     // RCCL communicator of the sample-sharded solvers (comm.hip; ncclComm_t kept opaque here)
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    // ... or a caller-supplied exchange (dcp_comm_set_external: MPI, gloo, a test double)
+    dcp_allreduce_fn comm_ext = nullptr;
+    void* comm_ext_user = nullptr;
     // a row gather registered by dcp_dict_prefetch_rows_bytes: the next dictionary step runs it on the side
     // stream beside its atom sweep (rows of the NEXT minibatch while the chip is nearly idle)
     const void* pf_in = nullptr;

@@ -46,7 +46,12 @@ def attach_communicator(device_tensor, group=None):
     if os.environ.get('DCP_SHARDED_LOOP', '') == 'python':
         return False
     if init and dist.get_backend(group) != 'nccl':
-        return False
+        # a process group RCCL cannot serve (gloo: several ranks may share one GPU).  The SAME in-library loops run
+        # with the exchange handed to the library as a callback (dcp_comm_set_external): the statistics are staged
+        # through pinned host memory and summed by torch.distributed on the CPU -- slow, for tests and rehearsals.
+        if world == 1:
+            return False
+        return _attach_external(device_tensor, group, rank, world, key)
     ident = [None]
     if rank == 0:
         buf = ctypes.create_string_buffer(_hip.COMM_ID_BYTES)
@@ -71,10 +76,55 @@ def attach_communicator(device_tensor, group=None):
     return True
 
 
+_EXTERNAL = {}      # device index -> (callback object, staging tensors): kept alive while the handle uses them
+
+
+def _attach_external(device_tensor, group, rank, world, key):
+    import torch
+    import torch.distributed as dist
+    lib, h = _arrays.lib_handle(device_tensor)
+    dev = device_tensor.device.index
+    staging = {}
+
+    def exchange(buf, count, dtype, stream, user):
+        try:
+            tdt = torch.float32 if dtype == 0 else torch.float64
+            st = staging.get(dtype)
+            if st is None or st.numel() < count:
+                st = torch.empty((int(count),), dtype=tdt, pin_memory=True)
+                staging[dtype] = st
+            nbytes = int(count) * st.element_size()
+            if lib.dcp_memcpy(h, ctypes.c_void_p(st.data_ptr()), ctypes.c_void_p(buf), nbytes) != _hip.OK:
+                return 1
+            torch.cuda.synchronize(dev)                        # everything up to the copy, on whatever stream
+            dist.all_reduce(st[:int(count)], op=dist.ReduceOp.SUM, group=group)
+            if lib.dcp_memcpy(h, ctypes.c_void_p(buf), ctypes.c_void_p(st.data_ptr()), nbytes) != _hip.OK:
+                return 2
+            return 0
+        except Exception:       # never let an exception cross the C frame
+            return 3
+    cb = _hip.ALLREDUCE_FN(exchange)
+    rc = lib.dcp_comm_set_external(h, ctypes.cast(cb, ctypes.c_void_p), None, rank, world)
+    if rc != _hip.OK:
+        return False
+    _EXTERNAL[dev] = (cb, staging)
+    _COMMS[dev] = key
+    return True
+
+
+def communicator_kind(device_tensor):
+    """'rccl', 'external' (dcp_comm_set_external callback) or None for this device's handle."""
+    dev = device_tensor.device.index
+    if dev not in _COMMS:
+        return None
+    return 'external' if dev in _EXTERNAL else 'rccl'
+
+
 def detach_communicator(device_tensor):
     lib, h = _arrays.lib_handle(device_tensor)
     _hip.check(h, lib.dcp_comm_destroy(h), 'dcp_comm_destroy')
     _COMMS.pop(device_tensor.device.index, None)
+    _EXTERNAL.pop(device_tensor.device.index, None)
 
 
 def comm_allreduce_(t):

@@ -79,8 +79,20 @@ const char* dcp_build_info(void);
  *   dcp_comm_allreduce_sum_* : in-place sum of buf[count] over the ranks, asynchronous on the handle's
  *                        stream (complex data: pass the interleaved (re, im) floats, count doubled).
  * librccl is bound at run time (the copy the process already holds, else the system one); without it
- * these calls return DCP_ERR_COMM and everything else of the library works. */
+ * these calls return DCP_ERR_COMM and everything else of the library works.
+ *   dcp_comm_set_external : instead of RCCL, the caller's own exchange (MPI, gloo, a test double): fn(buf, count,
+ *                        dtype (0 = float32, 1 = float64), hip_stream, user) must leave the element-wise sum over
+ *                        all ranks in the DEVICE array buf[count], ordered before anything enqueued on hip_stream
+ *                        afterwards (e.g. synchronise the stream, exchange through the host, copy back on the same
+ *                        stream), and return 0.  The sharded loops call it exactly where they would call
+ *                        ncclAllReduce; decomp_amd.sharded uses it for process groups RCCL cannot serve (gloo with
+ *                        several ranks on one GPU), so the SAME in-library loop runs in the two-rank tests.
+ *   dcp_memcpy         : hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault) on the handle's stream (what such a
+ *                        callback needs to stage through pinned host memory). */
 enum { DCP_COMM_ID_BYTES = 128 };
+typedef int (*dcp_allreduce_fn)(void* buf, int64_t count, int dtype, void* hip_stream, void* user);
+int dcp_comm_set_external(dcp_handle* h, dcp_allreduce_fn fn, void* user, int rank, int world);
+int dcp_memcpy(dcp_handle* h, void* dst, const void* src, int64_t bytes);
 int dcp_comm_unique_id(void* id_out, int64_t id_bytes);
 int dcp_comm_init(dcp_handle* h, const void* unique_id, int rank, int world);
 int dcp_comm_destroy(dcp_handle* h);

@@ -188,6 +188,9 @@ def _gloo_gpu_worker(rank, world, port, q, masked=False):
         it, D, x = sharded.nmf_solve_sharded(torch.from_numpy(y[rows]).cuda(),
                                              torch.from_numpy(D0).cuda(), tol=2e-3, maxiter=200,
                                              mask_local=torch.from_numpy(mask[rows]).cuda() if masked else None)
+        # round 4: the loop that ran is dcp_nmf_mu_sharded_* -- the in-library loop a multi-GPU rank executes -- with
+        # the exchange handed in as a callback over gloo (dcp_comm_set_external), not the Python loop
+        assert sharded.communicator_kind(D) == 'external'
         q.put((rank, it, D.cpu().numpy(), x.cpu().numpy()))
     finally:
         dist.destroy_process_group()
@@ -195,9 +198,10 @@ def _gloo_gpu_worker(rank, world, port, q, masked=False):
 
 @pytest.mark.parametrize('masked', [False, True])
 def test_sharded_two_ranks_on_one_gpu_gloo(masked):
-    """Two processes sharing the one GPU of the test box, statistics all-reduced over gloo:
-    the real HIP step kernels + the real collective logic with world_size = 2 (masked: the [K, 2F]
-    numerator | denominator statistics of configs[3]'s form cross the all-reduce)."""
+    """Two processes sharing the one GPU of the test box, statistics all-reduced over gloo: the IN-LIBRARY sharded
+    loop (dcp_nmf_mu_sharded_f32: statistics -> exchange -> replicated update, lagged stop test, discarded speculative
+    iteration) with world_size = 2 -- RCCL refuses two ranks on one GPU, so the exchange is the library's external
+    callback (masked: the [K, 2F] numerator | denominator statistics of configs[3]'s form cross the all-reduce)."""
     import os
     import torch.multiprocessing as mp
     import decomp_amd
