@@ -281,6 +281,8 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
             print('solve_cd_indexed host ms per step:', {k: round(1e3 * v / max(count, 1), 4) for k, v in tacc.items()},
                   'steps', count, flush=True)
         side.synchronize()      # the index uploads: nothing of this call is left on the side stream
+        # a registration the step never consumed (an error between the two calls) must not outlive the staging blocks
+        lib.dcp_dict_prefetch_rows_bytes(_hip.handle(dev.index), None, None, 0, 0, None)
     if pending is not None:
         pev, pslot, pit, pD = pending
         pev.synchronize()
