@@ -284,3 +284,23 @@ def test_coordinate_descent_exit_at_sweep_0_and_10_and_warm_start(dt):
     it3o, x3o = olasso.solve(y3.copy(), A.copy(), 0.05, tol=tol, method='cd', maxiter=200)
     assert it3 == it3o and it3 >= 10
     assert np.max(np.abs(x3 - x3o)) < eps * max(1.0, np.max(np.abs(x3o)))
+
+
+@pytest.mark.parametrize('method', ['ista', 'acc_ista', 'fista'])
+@pytest.mark.parametrize('maxiter', [1, 2, 10, 11, 12, 21])
+def test_proximal_gradient_iteration_count_edges(method, maxiter):
+    """Round 4 folded the solver's x * s / x / s passes into its first and last launches and reads the stop flag one
+    iteration late: the edges of that bookkeeping -- one iteration (first = check = last), the iteration after a check,
+    a check ON the last iteration (maxiter = 11, 21), exhaustion, and an early exit at iteration 0 or 10 -- against
+    the oracle, iteration counts exact (float64)."""
+    import decomp_amd as decomp
+    from oracle import lasso as olasso
+    rng = np.random.RandomState(maxiter)
+    N, F, K = 70, 33, 17
+    A = rng.randn(K, F)
+    y = (rng.randn(N, K) * (rng.uniform(size=(N, K)) < 0.3)) @ A + 0.05 * rng.randn(N, F)
+    for tol in (0.0, 1e-2, 1e3):          # never met / met at a later check / met at iteration 0
+        it, x = decomp.lasso.solve(y.copy(), A.copy(), 0.05, tol=tol, method=method, maxiter=maxiter)
+        ito, xo = olasso.solve(y.copy(), A.copy(), 0.05, tol=tol, method=method, maxiter=maxiter)
+        assert it == ito, (method, maxiter, tol, it, ito)
+        assert np.max(np.abs(x - xo)) < 1e-9 * max(1.0, np.max(np.abs(xo))), (method, maxiter, tol)
