@@ -47,6 +47,39 @@ __global__ void __launch_bounds__(256) c64_extend_left_kernel(const c64* __restr
     }
 }
 
+// G [32, 32] complex = the Hermitian combination of the sum of S real 64 x 64 slabs (stride apart), summed in a FIXED
+// two-level order (bitwise reproducible).  32 workgroups x 512 threads: workgroup a owns complex row a = real rows
+// 2a, 2a + 1 (128 contiguous floats of a slab); thread group q = tid / 128 sums slabs q, q + 4, ... in that order
+// (sixteen loads in flight), the four partial sums are added in the order q = 0..3, and 32 threads combine.  4 x the
+// parallelism of c64_gram_combine_kernel's flat ordered sum on a latency-bound 2 MB read.
+template <class T = c64>
+__global__ void __launch_bounds__(512) c64_gram_combine_tree_kernel(const float* __restrict__ slabs, int S, long stride,
+                                                                    c64* __restrict__ G) {
+    __shared__ float part[4][128];
+    __shared__ float row[128];
+    const int tid = threadIdx.x, e = tid & 127, q = tid >> 7;
+    const long i = blockIdx.x * 128L + e;
+    float acc = 0.0f;
+    int s = q;
+    for (; s + 60 < S; s += 64) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = slabs[(long)(s + 4 * u) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; s < S; s += 4) acc += slabs[(long)s * stride + i];
+    part[q][e] = acc;
+    __syncthreads();
+    if (tid < 128) row[tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+    __syncthreads();
+    if (tid < 32) {
+        const int bb = tid;
+        const float s00 = row[2 * bb], s01 = row[2 * bb + 1], s10 = row[64 + 2 * bb], s11 = row[64 + 2 * bb + 1];
+        G[blockIdx.x * 32 + bb] = c64{s00 + s11, s10 - s01};
+    }
+}
+
 // G [32, 32] complex = the Hermitian combination of the ordered sum of S real 64 x 64 slabs (stride apart).
 // 16 workgroups x 256 threads: a thread sums ONE real element over the slabs in their fixed order (sixteen loads in
 // flight; one at a time the loop is a chain of L2 round trips), a workgroup holds four consecutive real rows =
@@ -334,8 +367,8 @@ inline int atom_sweep_fused_c64(dcp_handle* h, const c64* A, const c64* B, c64* 
         hipLaunchKernelGGL(atom_apply_c64_kernel<c64>, dim3(ntile), dim3(256), 0, st, aa);
         DCP_LAUNCH_OK(h, hipGetLastError());
         if (has_next) {
-            hipLaunchKernelGGL(c64_gram_combine_kernel<c64>, dim3(16), dim3(256), 0, st, (const float*)slabs, ntile,
-                               64L * 64, w.G);
+            hipLaunchKernelGGL(c64_gram_combine_tree_kernel<c64>, dim3(32), dim3(512), 0, st, (const float*)slabs,
+                               ntile, 64L * 64, w.G);
             DCP_LAUNCH_OK(h, hipGetLastError());
         }
     }
