@@ -90,13 +90,17 @@ inline int dict_lasso(dcp_handle* h, const T* Y, const real_t<T>* M, int mask_nd
 template <class T>
 inline int dict_stats_core(dcp_handle* h, const T* Y, T* X, const T* D, int64_t Nb, int64_t F, int64_t K,
                            double alpha, int lasso_method, int lasso_iter, double lasso_tol, T* stats,
-                           int* lasso_it, LassoWs<T>& lw, DictWs<T>& dw, bool keep_slabs = false) {
+                           int* lasso_it, LassoWs<T>& lw, DictWs<T>& dw, bool keep_slabs = false,
+                           bool settle_later = false) {
     typedef real_t<T> R;
-    int it = 0;
+    // (a coordinate-descent solve may leave *it to be settled once its stop flag has landed -- lasso_settle_deferred --
+    //  so the iteration count is written straight into the caller's word, or into the handle's when there is none)
+    int* it = lasso_it ? lasso_it : &h->lasso_it_sink;
     DCP_TRY(dict_lasso<T>(h, Y, (const R*)nullptr, 0, D, X, Nb, F, K, alpha, lasso_tol, lasso_iter,
-                          lasso_method, &it, lw));
-    if (lasso_it) *lasso_it = it;
-    return dict_local_stats<T>(h, Y, X, Nb, F, K, stats, dw, keep_slabs);
+                          lasso_method, it, lw));
+    DCP_TRY(dict_local_stats<T>(h, Y, X, Nb, F, K, stats, dw, keep_slabs));
+    if (!settle_later) DCP_TRY(lasso_settle_deferred(h));
+    return DCP_OK;
 }
 
 template <class T>
@@ -184,7 +188,7 @@ inline int dict_step_core(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, 
     // one GPU: the statistics stay as ordered split-K partials (no [K, F+K] sum is formed: `stats` = null) and
     // are summed by the A / B accumulation itself
     DCP_TRY(dict_stats_core<T>(h, Y, X, D, Nb, F, K, alpha, lasso_method, lasso_iter, lasso_tol, (T*)nullptr,
-                               lasso_it, lw, dw, /*keep_slabs=*/true));
+                               lasso_it, lw, dw, /*keep_slabs=*/true, /*settle_later=*/true));
     // a registered prefetch (dcp_dict_prefetch_rows_bytes: the NEXT minibatch's rows into the OTHER staging block)
     // is started by dict_update in front of the atom sweep and runs on the side stream beside it, where the chip and
     // its HBM are nearly idle (beside the LASSO's iterations it measured 1 % slower, LassoExtra::start_prefetch);
@@ -195,6 +199,7 @@ inline int dict_step_core(dcp_handle* h, const T* Y, T* X, const T* D, T* Dnew, 
         DCP_TRY(main_after_side(h));
         h->pf_inflight = false;
     }
+    DCP_TRY(lasso_settle_deferred(h));   // *lasso_it of a cd solve: its flag landed while the rest was enqueued
     if (scal_out) *scal_out = md;
     return DCP_OK;
 }
@@ -258,6 +263,7 @@ inline int dict_mask_step_api(dcp_handle* h, const T* Y, const real_t<T>* M, T* 
     if (!Ym || !sB) return fail(h, DCP_ERR_INTERNAL, "dict workspace plan");
     int it = 0;
     DCP_TRY(dict_lasso<T>(h, Y, M, 2, D, X, Nb, F, K, alpha, lasso_tol, lasso_iter, lasso_method, &it, lw));
+    DCP_TRY(lasso_settle_deferred(h));   // (the masked solvers never defer; kept next to the local it belongs to)
     if (lasso_it) *lasso_it = it;
     // A3 <- beta A3 + x^H (x (x) m)
     hipLaunchKernelGGL((dict_mask_gram_kernel<T>), dim3((unsigned)F), dim3(256), 0, st, (const T*)X, M,

@@ -31,9 +31,10 @@ DCP_HD cx<R> div_scalar(cx<R> a, cx<R> b) {
 template <class T>
 __global__ void __launch_bounds__(256) dict_accumulate_kernel(const T* __restrict__ stats, long K, long F,
                                                               real_t<T> beta, T* __restrict__ A,
-                                                              T* __restrict__ B) {
+                                                              T* __restrict__ B, unsigned int* __restrict__ zero4) {
     const long W = F + K;
     const long n = K * W;
+    if (blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0u;   // gmax + ticket of maxabsdiff_publish_kernel
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
         const long r = i / W, c = i - r * W;
         const T v = stats[i];
@@ -48,9 +49,11 @@ template <class T>
 __global__ void __launch_bounds__(256) dict_accumulate_slabs_kernel(const T* __restrict__ slabs, long stride, int S,
                                                                     long K, long F, real_t<T> beta,
                                                                     T* __restrict__ A, T* __restrict__ B,
-                                                                    const T* __restrict__ Dsrc, T* __restrict__ Ddst) {
+                                                                    const T* __restrict__ Dsrc, T* __restrict__ Ddst,
+                                                                    unsigned int* __restrict__ zero4) {
     const long W = F + K;
     const long n = K * W;
+    if (blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0u;   // gmax + ticket of maxabsdiff_publish_kernel
     // (the sweep works in place on a copy of D: the copy rides along, one launch fewer)
     if (Dsrc != nullptr)
         for (long i = blockIdx.x * 256L + threadIdx.x; i < K * F; i += (long)gridDim.x * 256L) Ddst[i] = Dsrc[i];
@@ -95,6 +98,49 @@ __global__ void __launch_bounds__(256) maxabsdiff_partial_kernel(const T* __rest
     }
     R r = block_max_256(m, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// max_i |a_i - b_i| -> *out in ONE launch: a returning atomic max per workgroup (|.| >= 0: the bit pattern is monotone,
+// a NaN wins as in np.max), then an arrival ticket whose increment depends on the returned value; the workgroup that
+// arrives last stores the finished maximum (`out` may be device-mapped pinned host memory the caller polls).
+// scratch[0] (gmax) and the ticket behind it must be zero on entry: the step's accumulate kernel clears them.
+// (Few, large workgroups: the two atomics of every workgroup arrive in one burst at the end and same-address atomics
+// serialise at the memory side -- 512 workgroups of 256 threads spent 20 us here, 13 of them queueing.)
+template <class T>
+__global__ void __launch_bounds__(1024) maxabsdiff_publish_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                                  long n, real_t<T>* __restrict__ gmax,
+                                                                  unsigned int* __restrict__ ticket,
+                                                                  real_t<T>* __restrict__ out) {
+    typedef real_t<T> R;
+    __shared__ R sh[16];
+    R m = 0;
+    const long stride = (long)gridDim.x * 1024L;
+    long i = blockIdx.x * 1024L + threadIdx.x;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+        T va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { va[u] = a[i + u * stride]; vb[u] = b[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const R d = absval(sub(va[u], vb[u]));
+            m = (d > m || d != d) ? d : m;
+        }
+    }
+    for (; i < n; i += stride) {
+        const R d = absval(sub(a[i], b[i]));
+        m = (d > m || d != d) ? d : m;
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        R r = sh[0];
+        for (int w = 1; w < 16; ++w) r = (sh[w] > r || sh[w] != sh[w]) ? sh[w] : r;
+        unsigned int inc = 1u;
+        R old = atomic_max_nonneg_ret(gmax, r);
+        asm volatile("; the arrival is counted behind the max" : "+v"(inc) : "v"(old));
+        if (atomicAdd(ticket, inc) == gridDim.x - 1u) *out = atomic_read_nonneg(gmax);
+    }
 }
 
 // ---- masked dictionary learning (dictionary_learning.py:171-231) ----------------------------
@@ -245,11 +291,12 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
     hipStream_t st = h->stream;
     if (stats_nslabs > 0) {  // `stats` = ordered split-K partials (one GPU): sum and accumulate in one pass
         hipLaunchKernelGGL((dict_accumulate_slabs_kernel<T>), dim3(grid_for((long)K * (F + K))), dim3(256), 0, st,
-                           stats, (long)K * (F + K), stats_nslabs, (long)K, (long)F, beta, A, B, D, Dnew);
+                           stats, (long)K * (F + K), stats_nslabs, (long)K, (long)F, beta, A, B, D, Dnew,
+                           reinterpret_cast<unsigned int*>(w.partial));
         DCP_LAUNCH_OK(h, hipGetLastError());
     } else {
         hipLaunchKernelGGL((dict_accumulate_kernel<T>), dim3(grid_for((long)K * (F + K))), dim3(256), 0, st,
-                           stats, (long)K, (long)F, beta, A, B);
+                           stats, (long)K, (long)F, beta, A, B, reinterpret_cast<unsigned int*>(w.partial));
         DCP_LAUNCH_OK(h, hipGetLastError());
         DCP_HIP_OK(h, hipMemcpyAsync(Dnew, D, sizeof(T) * (size_t)K * F, hipMemcpyDeviceToDevice, st));
     }
@@ -288,12 +335,12 @@ inline int dict_update(dcp_handle* h, const T* stats, real_t<T> beta, T* A, T* B
         }
     }
     if (!fused) DCP_TRY(atom_sweep<T>(h, A, B, Dnew, F, K, w.atom));
-    const int mb = grid_for((long)K * F, 512);   // (w.partial holds >= 514 entries)
-    hipLaunchKernelGGL((maxabsdiff_partial_kernel<T>), dim3(mb), dim3(256), 0, st, D, (const T*)Dnew,
-                       (long)K * F, w.partial);
-    DCP_LAUNCH_OK(h, hipGetLastError());
-    hipLaunchKernelGGL((final_max_kernel<R>), dim3(1), dim3(256), 0, st, (const R*)w.partial, (long)mb,
-                       maxdiff_dev);
+    // max|D - D_new| in one launch (w.partial: 16 bytes = the running maximum + the arrival ticket, cleared by the
+    // accumulate kernel above)
+    long mb = ((long)K * F + 16 * 1024 - 1) / (16 * 1024);   // ~16 elements per thread
+    mb = mb < 1 ? 1 : (mb > 128 ? 128 : mb);
+    hipLaunchKernelGGL((maxabsdiff_publish_kernel<T>), dim3((unsigned)mb), dim3(1024), 0, st, D, (const T*)Dnew, (long)K * F,
+                       w.partial, reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(w.partial) + 8), maxdiff_dev);
     DCP_LAUNCH_OK(h, hipGetLastError());
     return DCP_OK;
 }

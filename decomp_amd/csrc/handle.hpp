@@ -25,7 +25,6 @@ struct dcp_handle {
     // ordered against the main stream with events only (side_after_main / main_after_side).
     hipStream_t side = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
-    hipEvent_t ev_flag = nullptr;   // behind the stop-flag copy of a LASSO check iteration (read one iteration late)
     // Workspace: one grow-only arena.  A public call plans its total need, reserves it
     // (ws_reserve: reallocates only when the plan outgrows the arena, i.e. on the first
     // call of a given problem size, never in steady state), then bumps (ws_alloc).
@@ -49,9 +48,12 @@ struct dcp_handle {
     void* pf_out = nullptr;
     int64_t pf_rows = 0, pf_row_bytes = 0;
     bool pf_inflight = false;   // started on the side stream, not yet joined
-    // coordinate descent: the previous solve on this handle met its stop test at sweep 0 (a warm-started,
-    // already converged problem): the next one launches that check sweep alone before committing to nine more
-    bool cd_warm = false;
+    // coordinate descent inside the dictionary step: the stop flag of the solve's last ten sweeps is still on its way
+    // to this pinned word when lasso_solve returns; lasso_settle_deferred() turns it into *lasso_deferred_it
+    int* lasso_deferred_flag = nullptr;
+    int* lasso_deferred_it = nullptr;
+    int lasso_deferred_it_met = 0;
+    int lasso_it_sink = 0;
     // parallel_cd inside the dictionary step: the caller-supplied shuffle table (dcp_dict_set_pcd_order)
     const int* pcd_order = nullptr;
     int64_t pcd_rows = 0, pcd_K = 0;
@@ -115,12 +117,16 @@ struct ProfScope {
     }
 };
 
+// Events that only order the handle's two streams on ONE device: no timing, and no system-scope fence when they are
+// recorded (the default's cache write-back idles the recording stream ~6 us; nothing on the host reads behind them).
+constexpr unsigned kOrderingEvent = hipEventDisableTiming | hipEventDisableSystemFence;
+
 // what is enqueued on h->side after this call starts after the work already on h->stream
 inline int side_after_main(dcp_handle* h) {
     if (h->side == nullptr) {
         if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&h->ev_main, kOrderingEvent) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_side, kOrderingEvent) != hipSuccess)
             return fail(h, DCP_ERR_HIP, "side stream creation failed");
     }
     if (hipEventRecord(h->ev_main, h->stream) != hipSuccess ||
@@ -162,7 +168,7 @@ inline void ws_order_streams(dcp_handle* h) {
     if (h->arena_stream_set && h->arena_stream != h->stream && h->arena != nullptr) {
         bool ok = false;
         if (h->stream_switch == nullptr)
-            (void)hipEventCreateWithFlags(&h->stream_switch, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&h->stream_switch, kOrderingEvent);
         if (h->stream_switch != nullptr && hipEventRecord(h->stream_switch, h->arena_stream) == hipSuccess &&
             hipStreamWaitEvent(h->stream, h->stream_switch, 0) == hipSuccess)
             ok = true;

@@ -333,7 +333,8 @@ template <class R>
 __global__ void __launch_bounds__(256) lasso_scalars_kernel(const R* __restrict__ s, long K, R alpha,
                                                             R tol, const R* __restrict__ nvalid_dev,
                                                             R nvalid_const, R* __restrict__ alphak,
-                                                            R* __restrict__ tolk) {
+                                                            R* __restrict__ tolk, int* __restrict__ flag_zero) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *flag_zero = 0;   // the stop flag starts every solve cleared
     const R nv = nvalid_dev != nullptr ? nvalid_dev[0] : nvalid_const;
     for (long k = blockIdx.x * 256L + threadIdx.x; k < K; k += (long)gridDim.x * 256L) {
         alphak[k] = (alpha / s[k]) * nv;
@@ -454,8 +455,12 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
                                                       const real_t<T>* __restrict__ alphak,
                                                       const real_t<T>* __restrict__ tolk, long rows,
                                                       int K, int nsweeps, int check_first,
-                                                      int* __restrict__ flag, T* __restrict__ snap) {
+                                                      int* __restrict__ flag, T* __restrict__ snap,
+                                                      const int* __restrict__ cond) {
     typedef real_t<T> R;
+    // the sweeps behind a check sweep whose test was met are not run (lasso.py:546-551 returns there): decided on
+    // the device from the check sweep's flag, so the host does not have to read it before launching them
+    if (cond != nullptr && *cond == 0) return;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -557,8 +562,10 @@ __global__ void __launch_bounds__(256) cd_gram_wide_kernel(T* __restrict__ X, T*
                                                            const real_t<T>* __restrict__ alphak,
                                                            const real_t<T>* __restrict__ tolk, long rows,
                                                            int K, int nsweeps, int check_first,
-                                                           int* __restrict__ flag, T* __restrict__ snap) {
+                                                           int* __restrict__ flag, T* __restrict__ snap,
+                                                           const int* __restrict__ cond) {
     typedef real_t<T> R;
+    if (cond != nullptr && *cond == 0) return;   // (see cd_gram_kernel)
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -841,6 +848,43 @@ inline int gram_kk(dcp_handle* h, const T* P, const T* Q, int K, int F, LassoWs<
     return DCP_OK;
 }
 
+// *host = *flag, *flag = 0: the stop flag of a check iteration goes to device-mapped pinned host memory (the host polls
+// it one iteration later) and is cleared for the next check.  One 2 us launch instead of a fill kernel in front of the
+// iteration, a copy kernel behind it and an event (whose barrier packet idles the GPU ~5 us): 14 -> ~3 us per check.
+template <class T = void>
+__global__ void flag_publish_kernel(int* __restrict__ flag, int* __restrict__ host) {
+    if (threadIdx.x == 0) {
+        const int f = *flag;
+        *flag = 0;
+        *host = f;
+    }
+}
+
+// Wait for flag_publish_kernel's store: the word was set to the sentinel -1 before that kernel was enqueued.  Polling
+// instead of sleeping in a blocking wait, which wakes up late (measured: the GPU sat idle ~2 ms per dictionary step
+// once the host ran a step ahead); a stream synchronisation is the fallback after ~2 s.
+inline int poll_host_flag(dcp_handle* h, int* host_flag) {
+    volatile int* vf = host_flag;
+    for (long spin = 0; spin < 400000000L; ++spin) {
+        if (*vf != -1) return DCP_OK;
+        __builtin_ia32_pause();
+    }
+    DCP_HIP_OK(h, hipStreamSynchronize(h->stream));
+    return DCP_OK;
+}
+
+// The dictionary step's deferred *it_out of a coordinate-descent solve (see the Gram-form loop in lasso_solve): called
+// once the rest of the step has been enqueued, when the flag has long landed.
+inline int lasso_settle_deferred(dcp_handle* h) {
+    if (h->lasso_deferred_flag == nullptr) return DCP_OK;
+    int* f = h->lasso_deferred_flag;
+    h->lasso_deferred_flag = nullptr;
+    DCP_TRY(poll_host_flag(h, f));
+    if (*f == 0 && h->lasso_deferred_it != nullptr) *h->lasso_deferred_it = h->lasso_deferred_it_met;
+    h->lasso_deferred_it = nullptr;
+    return DCP_OK;
+}
+
 template <class T>
 inline int read_flag(dcp_handle* h, int* flag_dev, int* host_flag, bool* violated) {
     DCP_HIP_OK(h, hipMemcpyAsync(host_flag, flag_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -887,6 +931,8 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
                        const LassoExtra& extra = LassoExtra()) {
     typedef real_t<T> R;
     hipStream_t st = h->stream;
+    h->lasso_deferred_flag = nullptr;   // (a deferral an earlier, failed call never settled dies here)
+    h->lasso_deferred_it = nullptr;
     const int N = (int)N64, F = (int)F64, K = (int)K64;
     void* hostv = nullptr;
     DCP_TRY(host_scratch(h, 64, &hostv));
@@ -921,7 +967,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
     DCP_LAUNCH_OK(h, hipGetLastError());
     hipLaunchKernelGGL((lasso_scalars_kernel<R>), dim3(grid_for(K, 64)), dim3(256), 0, st, w.s, (long)K,
                        alpha, tol, mask_ndim == 1 ? w.scal + 1 : (const R*)nullptr,
-                       mask_ndim == 2 ? R(1) : R(F), w.alphak, w.tolk);
+                       mask_ndim == 2 ? R(1) : R(F), w.alphak, w.tolk, w.flag);
     DCP_LAUNCH_OK(h, hipGetLastError());
     T* xcur = w.xb[0];
     // ista / acc_ista / fista without a 2-D mask: x * s is formed by hform_prepare_kernel in its pass over [N, K]
@@ -1109,24 +1155,23 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             a.ext_ws = w.ext2;
             DCP_LAUNCH_OK(h, (gemm<FORM_NN>(st, a, EpiSubFrom<T>{w.yAt, K, w.G, K})));
         }
-        // One launch = a check sweep (0, 10, 20, ...: lasso.py:546-551) and the up to nine sweeps after it; the
-        // codes after the check sweep are parked in a snapshot, the flag is read after the launch: when the test
-        // had passed, the snapshot is the answer and the extra sweeps (nearly free on converged codes: every
-        // step is a skipped zero step) are dropped.  Before: two launches and a host round trip per ten sweeps.
-        // A solve that meets the test at sweep 0 (warm start on converged codes: second visits of a minibatch with a
-        // loose lasso_tol) would still pay for the nine extra sweeps -- |dx| < tol is not dx = 0, so they are NOT
-        // free there.  When the previous solve on this handle ended that way, the check sweep is
-        // launched alone first and the other nine follow only if its test failed.
-        T* snap_buf = w.xb[1];
+        // Ten sweeps = a check sweep (0, 10, 20, ...: lasso.py:546-551) launched on its own and the up to nine sweeps
+        // behind it in a second launch that the DEVICE skips when the check sweep met the test (its flag is still
+        // zero): the codes are then exactly those the reference returns, and nothing on the host has to read the flag
+        // between the two launches.  The flag travels to pinned host memory behind them (flag_publish_kernel) and is
+        // polled only where the host needs it: to decide on ANOTHER ten sweeps, or for *it_out -- which the
+        // dictionary step defers to the end of the step (LassoExtra::no_final_sync), so that its default solve
+        // (cd x 10) puts no host round trip into the middle of the step.
+        // (Rounds 3-4 ran one launch per ten sweeps with the post-check codes parked in a snapshot and read the flag
+        // synchronously: ~37 us of idle GPU per solve in the kernel trace, plus a fill and a copy kernel.)
         int sweep = 0;
         result = xcur;
-        bool met = false;
         const int grid = (N + 3) / 4;
-        auto launch = [&](int ns, int check_first, T* snap) -> int {
+        auto launch = [&](int ns, int check_first, const int* cond) -> int {
 #define DCP_CD_LAUNCH(MM)                                                                            \
     hipLaunchKernelGGL((cd_gram_kernel<T, PROX, MM>), dim3(grid), dim3(256), 0, st, xcur, w.G,       \
                        (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,        \
-                       check_first, w.flag, snap)
+                       check_first, w.flag, (T*)nullptr, cond)
             // (the register form holds a row's K coefficients in one wave: 64 lanes x up to 32 slots;
             //  wider dictionaries take the memory-resident form -- the reference has no limit, lasso.py:526-552)
             if (K <= 64) DCP_CD_LAUNCH(1);
@@ -1138,7 +1183,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             else
                 hipLaunchKernelGGL((cd_gram_wide_kernel<T, PROX>), dim3(grid), dim3(256), 0, st, xcur, w.G,
                                    (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,
-                                   check_first, w.flag, snap);
+                                   check_first, w.flag, (T*)nullptr, cond);
 #undef DCP_CD_LAUNCH
             DCP_LAUNCH_OK(h, hipGetLastError());
             return DCP_OK;
@@ -1146,23 +1191,27 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         while (sweep < maxiter) {
             int last = sweep + 9;
             if (last > maxiter - 1) last = maxiter - 1;
-            const bool alone = (sweep == 0 && h->cd_warm && last > sweep);   // the check sweep on its own first
-            const int ns = alone ? 1 : last - sweep + 1;
-            T* snap = ns > 1 ? snap_buf : (T*)nullptr;
-            DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
-            DCP_TRY(launch(ns, 1, snap));
-            bool viol = true;
-            DCP_TRY(read_flag<T>(h, w.flag, host_flag, &viol));
-            if (!viol) {
-                it = sweep;
-                result = snap != nullptr ? snap : xcur;
-                met = true;
+            // (w.flag is zero here: lasso_scalars_kernel at the start of the solve, flag_publish_kernel afterwards)
+            DCP_TRY(launch(1, 1, nullptr));                                     // the check sweep
+            if (last > sweep) DCP_TRY(launch(last - sweep, 0, w.flag));         // sweeps sweep + 1 .. last, unless met
+            *reinterpret_cast<volatile int*>(host_flag) = -1;                   // sentinel: nothing has landed yet
+            hipLaunchKernelGGL(flag_publish_kernel<void>, dim3(1), dim3(64), 0, st, w.flag, host_flag);
+            DCP_LAUNCH_OK(h, hipGetLastError());
+            if (last == maxiter - 1 && extra.no_final_sync) {
+                // the last ten sweeps of a solve inside the dictionary step: *it_out is settled by
+                // lasso_settle_deferred() once the rest of the step has been enqueued
+                h->lasso_deferred_flag = host_flag;
+                h->lasso_deferred_it = it_out;
+                h->lasso_deferred_it_met = sweep;
                 break;
             }
-            if (alone) DCP_TRY(launch(last - sweep, 0, (T*)nullptr));        // sweeps 1 .. last, no test among them
+            DCP_TRY(poll_host_flag(h, host_flag));
+            if (*host_flag == 0) {
+                it = sweep;
+                break;
+            }
             sweep = last + 1;
         }
-        h->cd_warm = met && it == 0;
     } else if (method == DCP_LASSO_CD) {
         // ---------------- coordinate descent with a 2-D mask (as written) ----------------
         {   // r = y o M - (x An) o M
@@ -1234,29 +1283,16 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         bool converged = false;
         bool wrote_final = false;
         // The stop test of a check iteration (i % 10 == 0, lasso.py:293) is read ONE iteration late: its flag
-        // travels to the host behind an event while iteration i + 1 is already enqueued, so the GPU does not
+        // travels to the host (flag_publish_kernel) while iteration i + 1 is already enqueued, so the GPU does not
         // idle through a host round trip in the middle of every solve (the dictionary step runs ten
         // iterations and checks at i = 0).  Iteration i + 1 only READS iteration i's output, so when the test
         // had passed that output is still intact and i + 1 is simply discarded.
-        if (h->ev_flag == nullptr) DCP_HIP_OK(h, hipEventCreateWithFlags(&h->ev_flag, hipEventDisableTiming));
         int pend_i = -1;
         T* pend_x = nullptr;
         auto resolve = [&](bool* stop) -> int {
             *stop = false;
             if (pend_i < 0) return DCP_OK;
-            // The flag's copy lands in pinned host memory: poll that word (it was set to the sentinel -1 before
-            // the copy was enqueued) instead of sleeping in hipEventSynchronize -- a blocked wait wakes up late
-            // (measured: the GPU sat idle ~2 ms per dictionary step between iteration 1 and 2 once the host ran
-            // a step ahead); the event is the fallback after ~2 s of polling.
-            {
-                volatile int* vf = host_flag;
-                bool seen = false;
-                for (long spin = 0; spin < 400000000L; ++spin) {
-                    if (*vf != -1) { seen = true; break; }
-                    __builtin_ia32_pause();
-                }
-                if (!seen) DCP_HIP_OK(h, hipEventSynchronize(h->ev_flag));
-            }
+            DCP_TRY(poll_host_flag(h, host_flag));
             if (*host_flag == 0) {
                 it = pend_i;
                 result = pend_x;
@@ -1283,8 +1319,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
                 beta_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * beta * beta));     // lasso.py:411
                 coef = (R)((beta - 1.0) / beta_new);
             }
-            const int check = (i % 10 == 0) ? 1 : 0;
-            if (check) DCP_HIP_OK(h, hipMemsetAsync(w.flag, 0, sizeof(int), st));
+            const int check = (i % 10 == 0) ? 1 : 0;   // (w.flag is zero here: lasso_scalars_kernel, flag_publish_kernel)
             EpiProxStep<T, PROX> epi{w.yAt, V, P, Nw, mom ? Vn : (T*)nullptr, (long)K, w.scal,
                                      w.alphak, w.tolk, rowscale, coef, check, w.flag};
             const bool had_pending = pend_i >= 0;
@@ -1326,9 +1361,9 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
                 if (stop) break;   // this iteration is discarded
             }
             if (check) {
-                *reinterpret_cast<volatile int*>(host_flag) = -1;   // sentinel: no copy into it is pending here
-                DCP_HIP_OK(h, hipMemcpyAsync(host_flag, w.flag, sizeof(int), hipMemcpyDeviceToHost, st));
-                DCP_HIP_OK(h, hipEventRecord(h->ev_flag, st));
+                *reinterpret_cast<volatile int*>(host_flag) = -1;   // sentinel: nothing is in flight into it here
+                hipLaunchKernelGGL(flag_publish_kernel<void>, dim3(1), dim3(64), 0, st, w.flag, host_flag);
+                DCP_LAUNCH_OK(h, hipGetLastError());
                 pend_i = i;
                 pend_x = Nw;
             }

@@ -82,13 +82,20 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     DCP_TRY(host_scratch(h, sizeof(double) * (resid_blocks + 4), &hostv));
     T* host_md = reinterpret_cast<T*>(hostv);             // [2]
     double* host_part = reinterpret_cast<double*>(hostv) + 2;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    DCP_HIP_OK(h, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    DCP_HIP_OK(h, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-    struct EvGuard {
-        hipEvent_t* e;
-        ~EvGuard() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
-    } ev_guard{ev};
+    // The stop test polls the pinned word the normalisation's last workgroup stores max|dD| into (a sentinel of -1
+    // is put there before the iteration is enqueued; max|dD| >= 0 or NaN).  No event in the loop: the barrier packet of
+    // a hipEventRecord (system-scope release) cost ~6 us of idle GPU per iteration behind the normalisation.
+    auto wait_md = [&](int slot, T* out) -> int {
+        volatile T* v = host_md + slot;
+        bool seen = false;
+        for (long spin = 0; spin < 400000000L; ++spin) {
+            if (!(*v == T(-1))) { seen = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!seen) DCP_HIP_OK(h, hipStreamSynchronize(h->stream));   // ~2 s of polling: fall back to a blocking wait
+        *out = *v;
+        return DCP_OK;
+    };
 
     const T* Ypre = Y;
     if (masked) {  // y * mask is loop invariant (grads.py:114,124 recompute it every call)
@@ -101,7 +108,7 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     DCP_HIP_OK(h, hipMemsetAsync(ticket, 0, 4 * sizeof(unsigned int), h->stream));
 
     // Iteration `it` reads (x_{it-1}, D_{it-1}) from (Xc, Dc) and writes (x_it, D_it) to (Xn, Dn);
-    // its max|dD| is copied to host slot it&1 behind an event.  The stop test of iteration it-1
+    // its max|dD| lands in host slot it&1.  The stop test of iteration it-1
     // (batch_mu.py:22) is evaluated AFTER iteration it has been enqueued, so the GPU never
     // idles on the host; when it-1 turns out to have converged, iteration it is discarded:
     // its inputs (Xc, Dc) are exactly the state the reference returns.
@@ -119,10 +126,10 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
                                        std::is_same<T, float>::value ? COMM_F32 : COMM_F64));
         }
         // max|D - D_new| reaches the host without a copy kernel: the normalisation's last-arriving workgroup stores
-        // it into the pinned (device-mapped) slot, visible behind the event
+        // it into the pinned (device-mapped) slot, which the stop test polls
+        *reinterpret_cast<volatile T*>(host_md + slot) = T(-1);
         DCP_TRY(nmf_update<T>(h, stats, Dc, Dn, F, K, lik, masked, maxdiff_dev + slot, wu,
                               maxdiff_dev + (slot ^ 1), ticket, host_md + slot));
-        DCP_HIP_OK(h, hipEventRecord(ev[slot], h->stream));
         if (want_resid) {   // parity/debug mode: synchronous
             DCP_TRY(nmf_residual<T>(h, Y, mask, Xn, Dn, N, F, K, resid_tmp, resid_part,
                                     resid_blocks));
@@ -134,8 +141,7 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
             resid_trace[it - 1] = (T)sqrt(acc);
         }
         if (it > 1) {   // stop test of the PREVIOUS iteration
-            DCP_HIP_OK(h, hipEventSynchronize(ev[slot ^ 1]));
-            md_last = host_md[slot ^ 1];
+            DCP_TRY(wait_md(slot ^ 1, &md_last));
             if (md_last < tol) {   // a NaN compares false, as in NumPy
                 result_it = it - 1;
                 converged = true;
@@ -147,8 +153,7 @@ int nmf_mu_solve(dcp_handle* h, const T* Y, const T* mask, T* X, T* D, int64_t N
     }
     if (!converged && maxiter > 1) {   // stop test of the last iteration
         const int slot = (maxiter - 1) & 1;
-        DCP_HIP_OK(h, hipEventSynchronize(ev[slot]));
-        md_last = host_md[slot];
+        DCP_TRY(wait_md(slot, &md_last));
         if (md_last < tol) result_it = maxiter - 1;
     }
     DCP_HIP_OK(h, hipStreamSynchronize(h->stream));   // drain (incl. a discarded iteration)

@@ -461,7 +461,6 @@ int dcp_destroy(dcp_handle* h) {
         (void)hipStreamSynchronize(h->side);
         (void)hipStreamDestroy(h->side);
     }
-    if (h->ev_flag) (void)hipEventDestroy(h->ev_flag);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     delete h;

@@ -141,6 +141,20 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
     y_stage = [torch.empty((minibatch, F), dtype=y.dtype, device=dev) for _ in range(2)]
     x_stage = torch.empty((minibatch, K), dtype=x.dtype, device=dev)
     md_host = _pinned(torch, 'md', (2,), rdt)
+    md_np = md_host.numpy()                  # the same two words, read without a torch dispatch
+
+    def wait_maxdiff(slot):
+        # max|D - D_new| >= 0 (or NaN): the slot holds the sentinel -1 from just before its step was enqueued
+        # until the step's last kernel stores the value.  Polling instead of an event: the event's barrier packet
+        # (system-scope release) idles the GPU for ~6 us behind every step.
+        spins = 0
+        while md_np[slot] == -1.0:
+            spins += 1
+            if spins > 2000000:              # ~0.3 s: fall back to a blocking wait
+                main.synchronize()
+                break
+        return float(md_np[slot])
+
     # two preallocated pinned blocks for the epochs' row orders, filled by a plain single-threaded copy
     # (Tensor.pin_memory() per epoch would run torch's parallel CPU copy: on a many-core host its worker
     # threads spin after every call and starve the launching thread of its CPU share -- measured: 50-90 ms
@@ -214,7 +228,7 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
     gen = steps()
     cur = next(gen, None)
     count = 0
-    pending = None          # (event, slot, it, D_new) of the step before
+    pending = None          # (slot, it, D_new) of the step before
     ready = False           # y_stage[count & 1] already holds the current step's rows (prefetched)
     try:
         while cur is not None:
@@ -247,6 +261,7 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
             slot = count & 1
             # max|D - D_new| is written by the step's last kernel straight into pinned host memory (device-mapped: the
             # same pointer serves the GPU), no copy kernel behind the step
+            md_np[slot] = -1.0
             rc = step(h, _arrays.ptr(y_stage[buf]), _arrays.ptr(x_stage), _arrays.ptr(D), _arrays.ptr(D_new),
                       _arrays.ptr(A), _arrays.ptr(B), minibatch, F, K, float(beta), float(alpha), code,
                       int(lasso_iter), float(lasso_tol), _arrays.ptr(md_host[slot:slot + 1]),
@@ -254,13 +269,10 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
             _hip.check(h, rc, 'dcp_dict_step_async_' + sfx)
             t3 = _time.perf_counter()
             tacc['step_call'] += t3 - t2
-            ev = torch.cuda.Event()
-            ev.record(main)
             # stop test of the PREVIOUS step (:161-162), now that this one is enqueued
             if pending is not None:
-                pev, pslot, pit, pD = pending
-                pev.synchronize()
-                if float(md_host[pslot]) < tol:
+                pslot, pit, pD = pending
+                if wait_maxdiff(pslot) < tol:
                     # this step ran speculatively on the converged dictionary: its codes are not
                     # scattered, its A / B / D_new are dropped
                     return pit, pD, x
@@ -268,13 +280,13 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
             tacc['stop_test_wait'] += t4 - t3
             _move_rows('dcp_scatter_rows_bytes', x_stage, idx, minibatch, row_bytes_x, x)
             tacc['scatter'] += _time.perf_counter() - t4
-            pending = (ev, slot, it, D_new)
+            pending = (slot, it, D_new)
             D, D_new = D_new, D
             count += 1
             cur = nxt
     except KeyboardInterrupt:                                            # :166-167
         torch.cuda.synchronize(dev)
-        return (pending[2] if pending else 1), D, x
+        return (pending[1] if pending else 1), D, x
     finally:
         if trace:
             print('setup ms %.3f loop total ms %.3f' % (1e3 * (t_loop0 - t_fn0), 1e3 * (_time.perf_counter() - t_loop0)), flush=True)
@@ -284,9 +296,8 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
         # a registration the step never consumed (an error between the two calls) must not outlive the staging blocks
         lib.dcp_dict_prefetch_rows_bytes(_hip.handle(dev.index), None, None, 0, 0, None)
     if pending is not None:
-        pev, pslot, pit, pD = pending
-        pev.synchronize()
-        if float(md_host[pslot]) < tol:
+        pslot, pit, pD = pending
+        if wait_maxdiff(pslot) < tol:
             return pit, pD, x
     return maxiter, D, x
 
