@@ -277,8 +277,7 @@ inline int dict_local_stats(dcp_handle* h, const T* Y, const T* X, int64_t Nb, i
     w.stat_nslabs = a.ksplits;
     if (keep_slabs) return DCP_OK;
     if (!stats) return fail(h, DCP_ERR_INTERNAL, "dict_local_stats: stats is null");
-    hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * W)), dim3(256), 0, h->stream,
-                       w.slabs, (long)K * W, a.ksplits, (long)K * W, stats);
+    launch_reduce_slabs<T>(h->stream, w.slabs, (long)K * W, a.ksplits, (long)K * W, stats);
     DCP_LAUNCH_OK(h, hipGetLastError());
     return DCP_OK;
 }

@@ -445,17 +445,15 @@ __global__ void __launch_bounds__(256) vec_sum_kernel(const R* __restrict__ v, l
 // sequence of applied updates is exactly that of the sequential sweep (lasso.py:539-548); with
 // sparse codes a sweep costs ~(#changed coordinates) steps instead of K.
 // Sweeps [.., + nsweeps); the FIRST one is a check sweep when check_first != 0 (the reference tests on
-// sweeps 0, 10, 20, ...: a launch starts at one and runs on through the nine after it).  `snap` (nullable):
-// the codes as they stand after that first sweep -- what the reference returns when the test passes there
-// (lasso.py:546-551); the host reads the flag after the launch and takes the snapshot instead of the
-// result of the extra sweeps, so a solve costs one launch and one host round trip per ten sweeps.
+// sweeps 0, 10, 20, ...).  `cond` (nullable): the flag of the check sweep launched just before -- zero means its
+// test was met and the reference returned there (lasso.py:546-551), so this launch does nothing.
 template <class T, int PROX, int MAXM>
 __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __restrict__ G,
                                                       const T* __restrict__ AAt,
                                                       const real_t<T>* __restrict__ alphak,
                                                       const real_t<T>* __restrict__ tolk, long rows,
                                                       int K, int nsweeps, int check_first,
-                                                      int* __restrict__ flag, T* __restrict__ snap,
+                                                      int* __restrict__ flag,
                                                       const int* __restrict__ cond) {
     typedef real_t<T> R;
     // the sweeps behind a check sweep whose test was met are not run (lasso.py:546-551 returns there): decided on
@@ -485,13 +483,6 @@ __global__ void __launch_bounds__(256) cd_gram_kernel(T* __restrict__ X, T* __re
     bool viol = false;
     for (int s = 0; s < nsweeps; ++s) {
         const bool check = check_first && (s == 0);
-        if (s == 1 && snap != nullptr) {   // the codes after the check sweep
-#pragma unroll
-            for (int m = 0; m < MAXM; ++m) {
-                const int c = lane + 64 * m;
-                if (m < M && c < K) snap[row * K + c] = x[m];
-            }
-        }
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) {
             if (m >= M) break;
@@ -562,7 +553,7 @@ __global__ void __launch_bounds__(256) cd_gram_wide_kernel(T* __restrict__ X, T*
                                                            const real_t<T>* __restrict__ alphak,
                                                            const real_t<T>* __restrict__ tolk, long rows,
                                                            int K, int nsweeps, int check_first,
-                                                           int* __restrict__ flag, T* __restrict__ snap,
+                                                           int* __restrict__ flag,
                                                            const int* __restrict__ cond) {
     typedef real_t<T> R;
     if (cond != nullptr && *cond == 0) return;   // (see cd_gram_kernel)
@@ -575,8 +566,6 @@ __global__ void __launch_bounds__(256) cd_gram_wide_kernel(T* __restrict__ X, T*
     bool viol = false;
     for (int s = 0; s < nsweeps; ++s) {
         const bool check = check_first && (s == 0);
-        if (s == 1 && snap != nullptr)     // the codes after the check sweep (see cd_gram_kernel)
-            for (int c = lane; c < K; c += 64) snap[row * K + c] = xrow[c];
         for (int m = 0; m < M; ++m) {
             const int c0 = lane + 64 * m;
             const bool ok = c0 < K;
@@ -989,8 +978,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
         const int ys = (stride >= (long)N * K && w.xb[3] - w.xb[2] == stride) ? plan_deep_nt(a, 3) : 1;
         if (ys > 1) {
             DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a, EpiSlab<T>{w.xb[1], K, stride})));
-            hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, st,
-                               (const T*)w.xb[1], stride, ys, (long)N * K, w.yAt);
+            launch_reduce_slabs<T>(st, (const T*)w.xb[1], stride, ys, (long)N * K, w.yAt);
             DCP_LAUNCH_OK(h, hipGetLastError());
         } else {
             DCP_LAUNCH_OK(h, (gemm<FORM_NT>(st, a, EpiStore<T>{w.yAt, K})));
@@ -1171,7 +1159,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
 #define DCP_CD_LAUNCH(MM)                                                                            \
     hipLaunchKernelGGL((cd_gram_kernel<T, PROX, MM>), dim3(grid), dim3(256), 0, st, xcur, w.G,       \
                        (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,        \
-                       check_first, w.flag, (T*)nullptr, cond)
+                       check_first, w.flag, cond)
             // (the register form holds a row's K coefficients in one wave: 64 lanes x up to 32 slots;
             //  wider dictionaries take the memory-resident form -- the reference has no limit, lasso.py:526-552)
             if (K <= 64) DCP_CD_LAUNCH(1);
@@ -1183,7 +1171,7 @@ inline int lasso_solve(dcp_handle* h, const T* Y, const real_t<T>* mask, int mas
             else
                 hipLaunchKernelGGL((cd_gram_wide_kernel<T, PROX>), dim3(grid), dim3(256), 0, st, xcur, w.G,
                                    (const T*)w.AAt, (const R*)w.alphak, (const R*)w.tolk, (long)N, K, ns,
-                                   check_first, w.flag, (T*)nullptr, cond);
+                                   check_first, w.flag, cond);
 #undef DCP_CD_LAUNCH
             DCP_LAUNCH_OK(h, hipGetLastError());
             return DCP_OK;

@@ -334,8 +334,7 @@ inline int nmf_stats(dcp_handle* h, const T* Ypre, const T* mask, const T* Xin, 
     }
     ProfScope ps(h, DCP_PROF_STATS_SUM);
     if (Wg == W) {
-        hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(grid_for((long)K * W)), dim3(256), 0, st,
-                           w.slabs, (long)K * W, sa.ksplits, (long)K * W, stats);
+        launch_reduce_slabs<T>(st, w.slabs, (long)K * W, sa.ksplits, (long)K * W, stats);
         DCP_LAUNCH_OK(h, hipGetLastError());
     } else {
         // KL without mask: numerator from the GEMM, denominator = colsum(x) broadcast over F

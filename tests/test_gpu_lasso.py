@@ -256,11 +256,11 @@ def test_wide_coordinate_descent_equals_register_form_bitwise(monkeypatch):
 
 @pytest.mark.parametrize('dt', ['float64', 'float32'])
 def test_coordinate_descent_exit_at_sweep_0_and_10_and_warm_start(dt):
-    """one coordinate-descent launch = the check sweep + up to nine more, the codes after the check sweep
-    parked in a snapshot that IS the answer when the test passed there (lasso.py:546-551).  Pins the snapshot path
-    (exit at sweep 0), a later check (exit at sweep 10 / 20) and the warm-start regime -- a second solve from the
-    converged codes exits at sweep 0 (then the check sweep is launched alone) -- against the oracle's as-written
-    sweep: iteration counts identical, codes to rounding."""
+    """Ten coordinate-descent sweeps = the check sweep in a launch of its own + up to nine more in a second launch
+    that the device skips when the check sweep met the test (lasso.py:546-551; rounds 3-4 parked the post-check codes
+    in a snapshot instead).  Pins the exit at sweep 0, a later check (exit at sweep 10 / 20) and the warm-start
+    regime -- a second solve from the converged codes exits at sweep 0 -- against the oracle's as-written sweep:
+    iteration counts identical, codes to rounding."""
     import decomp_amd as decomp
     from oracle import lasso as olasso
     rng = np.random.RandomState(12)
@@ -273,12 +273,12 @@ def test_coordinate_descent_exit_at_sweep_0_and_10_and_warm_start(dt):
     ito, xo = olasso.solve(y.copy(), A.copy(), 0.05, tol=tol, method='cd', maxiter=200)
     assert it1 == ito and it1 >= 10 and it1 % 10 == 0                 # met at a LATER check sweep
     assert np.max(np.abs(x1 - xo)) < eps * max(1.0, np.max(np.abs(xo)))
-    for _ in range(2):      # warm starts: the first sets the handle's hint, the second runs the lone check sweep
+    for _ in range(2):      # warm starts: the nine sweeps behind the check sweep are skipped on the device
         it2, x2 = decomp.lasso.solve(y.copy(), A.copy(), 0.05, x=x1.copy(), tol=tol, method='cd', maxiter=200)
         it2o, x2o = olasso.solve(y.copy(), A.copy(), 0.05, x=xo.copy(), tol=tol, method='cd', maxiter=200)
-        assert it2 == it2o == 0                                        # met at sweep 0: the snapshot / lone sweep
+        assert it2 == it2o == 0                                        # met at sweep 0
         assert np.max(np.abs(x2 - x2o)) < eps * max(1.0, np.max(np.abs(xo)))
-    # a cold problem right after (the hint says "warm"): the lone check sweep fails, nine more follow
+    # a cold problem right after: the check sweep fails, nine more follow
     y3 = (y + 0.5 * rng.randn(N, F)).astype(dt)
     it3, x3 = decomp.lasso.solve(y3.copy(), A.copy(), 0.05, tol=tol, method='cd', maxiter=200)
     it3o, x3o = olasso.solve(y3.copy(), A.copy(), 0.05, tol=tol, method='cd', maxiter=200)
