@@ -25,18 +25,31 @@ A = torch.zeros((K, K), device=device, dtype=dt)
 B = torch.zeros((K, F), device=device, dtype=dt)
 Dn = torch.empty_like(D)
 _, h = _arrays.lib_handle(Y)
-fn = getattr(lib, 'dcp_dict_step_' + ('c64' if cplx else 'f32'))
+sfx = 'c64' if cplx else 'f32'
+use_async = os.environ.get('ASYNC', '1') == '1'      # the entry dictionary_learning.solve() drives (max|dD| read a step late)
+fn = getattr(lib, ('dcp_dict_step_async_' if use_async else 'dcp_dict_step_') + sfx)
 md = ctypes.c_double(0); lit = ctypes.c_int(0)
+md_pin = torch.zeros((2,), dtype=torch.float32).pin_memory()
+md_np = md_pin.numpy()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 n_steps = int(os.environ.get('STEPS', 8))
 for i in range(n_steps):
     if i == 2:
         e0.record()
     theta = i * MB + 1.0
+    if use_async:
+        md_np[i & 1] = -1.0
+        out = _arrays.ptr(md_pin[(i & 1):(i & 1) + 1])
+    else:
+        out = ctypes.byref(md)
     _hip.check(h, fn(h, _arrays.ptr(Y), _arrays.ptr(x), _arrays.ptr(D), _arrays.ptr(Dn), _arrays.ptr(A), _arrays.ptr(B),
-                     MB, F, K, (theta - MB) / theta, 0.1, method, 10, 1e-5, ctypes.byref(md), ctypes.byref(lit)), 'dict_step')
+                     MB, F, K, (theta - MB) / theta, 0.1, method, 10, 1e-5, out, ctypes.byref(lit)), 'dict_step')
+    if use_async and i > 0:
+        while md_np[(i & 1) ^ 1] == -1.0:
+            pass
     D, Dn = Dn, D
 e1.record()
 torch.cuda.synchronize()
-print('dictionary step (%s, %s) %dx%d k=%d: %.4f ms' % ('c64' if cplx else 'f32', os.environ.get('METHOD', 'ista'), MB, F, K,
-                                                         e0.elapsed_time(e1) / (n_steps - 2)))
+print('dictionary step (%s, %s, %s entry) %dx%d k=%d: %.4f ms' % (sfx, os.environ.get('METHOD', 'ista'),
+                                                                   'async' if use_async else 'blocking', MB, F, K,
+                                                                   e0.elapsed_time(e1) / (n_steps - 2)))
