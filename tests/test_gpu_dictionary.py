@@ -491,3 +491,61 @@ def test_async_step_and_registered_prefetch_equal_the_synchronous_step():
             assert torch.equal(a[i], b[i]), (sfx, i)
         assert a[5] == b[5] and abs(a[4] - b[4]) <= 1e-12 * max(1.0, abs(a[4]))
         assert torch.equal(b[6], Yall[idx_next])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', ['float32', 'float64', 'complex64'])
+def test_coordinate_descent_inside_the_step_settles_its_iteration_count(dt):
+    """Inside the dictionary step a coordinate-descent solve no longer reads its stop flag between the check sweep and
+    the nine sweeps behind it: the device skips them when the test was met, and *lasso_it is settled at the end of the
+    step (lasso_settle_deferred).  Both outcomes -- met at sweep 0 (warm start on converged codes: it = 0, codes those
+    after ONE sweep) and not met (it = lasso_iter - 1) -- must give the codes and the count of the standalone solve
+    (decomp_amd.lasso.solve, itself pinned against the oracle and the reference fixtures), through the blocking and
+    the asynchronous entry."""
+    import ctypes
+    import torch
+    import decomp_amd as decomp
+    from decomp_amd import _arrays, _hip
+    tdt = getattr(torch, dt)
+    cplx = dt.startswith('complex')
+    sfx = {'float32': 'f32', 'float64': 'f64', 'complex64': 'c64'}[dt]
+    rdt = torch.float64 if dt == 'float64' else torch.float32
+    g = torch.Generator(device='cuda')
+    g.manual_seed(11)
+    MB, F, K = 192, 96, 40
+
+    def randn(*sh):
+        r = torch.randn(sh, generator=g, device='cuda', dtype=rdt)
+        return torch.complex(r, torch.randn(sh, generator=g, device='cuda', dtype=rdt)) if cplx else r
+    D = randn(K, F)
+    _arrays.l2_normalize_(D, strict=True)
+    xt = randn(MB, K) * (torch.rand((MB, K), generator=g, device='cuda') < 0.15).to(rdt)
+    Y = (xt @ D + 0.05 * randn(MB, F)).contiguous()
+    lib, h = _arrays.lib_handle(D)
+    tol = 1e-3 if dt != 'float64' else 1e-7
+    alpha = 0.002           # (the solver scales it by n_channels: lasso.py:135-138)
+    # converged codes to warm-start from
+    it_c, x_conv = decomp.lasso.solve(Y, D, alpha, tol=tol, method='cd', maxiter=500)
+    assert 0 < it_c < 499 and int((x_conv != 0).sum()) > 0
+    for x0, want_met in ((x_conv, True), (torch.ones((MB, K), device='cuda', dtype=tdt), False)):
+        it_ref, x_ref = decomp.lasso.solve(Y, D, alpha, x=x0.clone(), tol=tol, method='cd', maxiter=10)
+        assert (it_ref == 0) == want_met
+        for entry in ('dcp_dict_step_', 'dcp_dict_step_async_'):
+            x = x0.clone()
+            A = torch.zeros((K, K), device='cuda', dtype=tdt)
+            B = torch.zeros((K, F), device='cuda', dtype=tdt)
+            Dn = torch.empty_like(D)
+            lit = ctypes.c_int(-7)
+            if entry.endswith('async_'):
+                md = torch.zeros((1,), device='cuda', dtype=rdt)
+                out = _arrays.ptr(md)
+            else:
+                mdc = ctypes.c_double(0)
+                out = ctypes.byref(mdc)
+            _hip.check(h, getattr(lib, entry + sfx)(
+                h, _arrays.ptr(Y), _arrays.ptr(x), _arrays.ptr(D), _arrays.ptr(Dn), _arrays.ptr(A), _arrays.ptr(B),
+                MB, F, K, (1.0 - MB) / 1.0, alpha, _hip.LASSO_CD, 10, tol, out, ctypes.byref(lit)), entry)
+            torch.cuda.synchronize()
+            assert lit.value == it_ref, (dt, entry, want_met, lit.value, it_ref)
+            assert torch.equal(x, x_ref), (dt, entry, want_met)
+            assert bool(torch.isfinite(torch.view_as_real(Dn) if cplx else Dn).all())
