@@ -425,6 +425,12 @@ int dcp_dict_set_pcd_order(dcp_handle* h, const int32_t* order, int64_t rows, in
  *   dcp_dict_step_async_* : the same step with max|D - D_new| left in the DEVICE scalar maxdiff_dev and no
  *                       wait for the GPU: the caller evaluates the stop test (line 161-162) one step late,
  *                       when the next minibatch is already enqueued (decomp_amd.dictionary_learning).
+ *                       maxdiff_dev may be device memory or pinned, device-mapped host memory (hipHostMalloc): the
+ *                       step's last kernel stores the value with a plain store, so a caller that puts a sentinel
+ *                       (-1; max|.| >= 0 or NaN) into a pinned word before the call can poll it instead of
+ *                       recording an event -- a recorded event is a barrier packet that idles the stream ~6 us.
+ *                       *lasso_it (host) is final when the call returns (a coordinate-descent solve settles it at the
+ *                       end of the step, when its stop flag has landed in pinned memory; nothing waits mid-step).
  * D [K,F] must be l2_strict-normalised by the caller on entry of the run (line 126); A [K,K]
  * and B [K,F] are the running statistics (zero before the first step). */
 int dcp_dict_stats_f32(dcp_handle* h, const float* Y, float* X, const float* D, int64_t Nb, int64_t F,
