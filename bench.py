@@ -403,10 +403,23 @@ def secondary_configs(torch, device, with_oracle=False):
     kw = dict(tol=0.0, minibatch=MB, lasso_method='ista', lasso_iter=10, lasso_tol=1e-5, random_seed=0)
     decomp_amd.dictionary_learning.solve(Yfull, D, 0.1, maxiter=2, **kw)          # warm-up: one epoch
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    it_e2e, D_e2e, x_e2e = decomp_amd.dictionary_learning.solve(Yfull, D, 0.1, maxiter=4, **kw)
-    torch.cuda.synchronize()
-    e2e_ms = 1e3 * (time.perf_counter() - t0) / (3 * (NT // MB))
+
+    def throttled_periods():
+        try:
+            for ln in open('/sys/fs/cgroup/cpu.stat'):
+                if ln.startswith('nr_throttled'):
+                    return int(ln.split()[1])
+        except Exception:
+            pass
+        return None
+    thr0 = throttled_periods()
+    e2e_samples = []
+    for _ in range(3):      # three identical calls: the median is reported, every sample is listed
+        t0 = time.perf_counter()
+        it_e2e, D_e2e, x_e2e = decomp_amd.dictionary_learning.solve(Yfull, D, 0.1, maxiter=4, **kw)
+        torch.cuda.synchronize()
+        e2e_samples.append(1e3 * (time.perf_counter() - t0) / (3 * (NT // MB)))
+    e2e_ms = sorted(e2e_samples)[1]
     # the same call with maxiter = 13 (12 epochs = 96 steps): the per-call cost -- the first permutation of 65536 row
     # indices on the host, allocations, pipeline fill and drain, ~2 ms -- spread over a call of realistic length
     # (the reference's default is maxiter = 1000)
@@ -416,14 +429,21 @@ def secondary_configs(torch, device, with_oracle=False):
     e2e_long_ms = 1e3 * (time.perf_counter() - t0) / (12 * (NT // MB))
     out['dictionary_learning_solve_ms_per_step'] = {
         'workload': 'configs[2] END TO END: decomp_amd.dictionary_learning.solve(Y 65536x4096 fp32 on the device, k=512, '
-                    'minibatch=8192, lasso_method=ista, lasso_iter=10, maxiter=4): wall clock of the call / 24 steps',
-        'value': round(e2e_ms, 4), 'it': int(it_e2e),
+                    'minibatch=8192, lasso_method=ista, lasso_iter=10, maxiter=4): wall clock of the call / 24 steps, median of 3 calls',
+        'value': round(e2e_ms, 4), 'samples_ms': [round(v, 4) for v in e2e_samples], 'it': int(it_e2e),
         'finite': bool(torch.isfinite(D_e2e).all().item()) and bool(torch.isfinite(x_e2e).all().item()),
         'code_density': float((x_e2e != 0).float().mean().item()),
         'vs_step_kernel_figure': round(e2e_ms / out['dictionary_step_ms']['value'], 4),
         'maxiter_13_96_steps': {'value': round(e2e_long_ms, 4), 'it': int(it_long),
                                 'finite': bool(torch.isfinite(D_long).all().item()),
-                                'vs_step_kernel_figure': round(e2e_long_ms / out['dictionary_step_ms']['value'], 4)}}
+                                'vs_step_kernel_figure': round(e2e_long_ms / out['dictionary_step_ms']['value'], 4),
+                                'vs_async_step': round(e2e_long_ms / out['dictionary_step_ms']['async_entry_ms'], 4)},
+        'vs_async_step': round(e2e_ms / out['dictionary_step_ms']['async_entry_ms'], 4)}
+    thr1 = throttled_periods()
+    if thr0 is not None and thr1 is not None:
+        # CFS periods in which this container was throttled while the end-to-end calls ran (0 on a quiet run; a
+        # throttled launching thread shows up as tens of ms in one sample)
+        out['dictionary_learning_solve_ms_per_step']['cgroup_throttled_periods'] = thr1 - thr0
     del D_long, x_long
     del Yfull, D_e2e, x_e2e, D, Dt
 
@@ -582,6 +602,13 @@ def main():
     import torch
     import torch.distributed as dist
     from decomp_amd import _arrays, _hip, sharded
+
+    # torch's CPU thread pool defaults to one thread per host CPU (256 here) whatever the container's quota (16):
+    # its workers spin after every parallel region and get the whole cgroup throttled -- the launching thread then
+    # sits out the rest of the 100 ms period (profiles/r04_dictionary_learning_e2e.txt).  Cap it like the BLAS pool.
+    quota0 = cgroup_cpu_quota()
+    if quota0:
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), int(quota0))))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
