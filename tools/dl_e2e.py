@@ -18,8 +18,20 @@ res = []
 for rep in range(int(os.environ.get('REPS', '4'))):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if os.environ.get('DCP_DL_TRACE', '0') == '1':
+        print('call starts at 0', flush=True)
+        import decomp_amd.dictionary_learning as _dl
+        _orig = _dl.solve_cd_indexed
+        def _stamped(*a, **k):
+            print('solve_cd_indexed entered after %.3f ms' % (1e3 * (time.perf_counter() - t0)), flush=True)
+            r = _orig(*a, **k)
+            print('solve_cd_indexed returned after %.3f ms' % (1e3 * (time.perf_counter() - t0)), flush=True)
+            return r
+        _dl.solve_cd_indexed = _stamped
     it, D, x = decomp_amd.dictionary_learning.solve(Y, D0, 0.1, **kw)
     t_ret = time.perf_counter()
+    if os.environ.get('DCP_DL_TRACE', '0') == '1':
+        _dl.solve_cd_indexed = _orig
     torch.cuda.synchronize()
     if os.environ.get('DCP_DL_TRACE', '0') == '1':
         print('solve() returned after %.3f ms, final sync %.3f ms' % (1e3 * (t_ret - t0), 1e3 * (time.perf_counter() - t_ret)), flush=True)
