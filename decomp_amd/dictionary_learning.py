@@ -150,6 +150,8 @@ def solve_cd_indexed(y, D, alpha, x, tol, minibatch, maxiter,
         spins = 0
         while md_np[slot] == -1.0:
             spins += 1
+            if (spins & 63) == 0:
+                _time.sleep(0)               # hand the GIL over: the helper thread draws the next epoch's order
             if spins > 2000000:              # ~0.3 s: fall back to a blocking wait
                 main.synchronize()
                 break
